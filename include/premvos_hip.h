@@ -1,0 +1,141 @@
+/*
+ * premvos_hip.h -- C-ABI of libpremvos_hip.so: the MI355X (gfx950) kernels behind the
+ * PReMVOS per-frame dense hot path (PWC-Net flow, proposal_net, refinement_net forward).
+ *
+ * Boundary rules:
+ *   - extern "C", raw DEVICE pointers + explicit sizes/strides, caller-owned buffers;
+ *   - every entry point is asynchronous on the hipStream_t handed in (void* here so the
+ *     header needs no HIP include), no hidden synchronisation, no global state;
+ *   - returns 0 on success, <0 on argument / launch error (message: premvos_last_error()),
+ *     never exit()s -- unlike the reference FFI, which "returns 1 always" and exit(-1)s on
+ *     a failed launch (correlation_package/src/corr_cuda.c:80, corr_cuda_kernel.cu:49-54).
+ *
+ * Layout: activations are NHWC ("pixel major") fp32 with an explicit pixel stride `ps`
+ * (in elements) so a tensor may be a channel slice [coff, coff+C) of a wider concat
+ * buffer: pass `base + coff` and the buffer's `ps`.  Slices used as conv INPUT need
+ * (pointer % 16 B == 0), ps % 4 == 0 and roundup(C,4) readable finite floats per pixel.
+ *
+ * The reference interface each function replaces is cited as file:line relative to
+ * /root/reference/code/.
+ */
+#ifndef PREMVOS_HIP_H
+#define PREMVOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PREMVOS_OK 0
+#define PREMVOS_EINVAL (-1)
+#define PREMVOS_ELAUNCH (-2)
+
+/* activation enum for the fused conv epilogue */
+#define PREMVOS_ACT_NONE 0
+#define PREMVOS_ACT_RELU 1
+#define PREMVOS_ACT_LEAKY 2 /* x > 0 ? x : slope * x   (nn.LeakyReLU(0.1), PWCNet.py:28) */
+
+/* output scatter mode of the conv epilogue */
+#define PREMVOS_OUT_NHWC 0
+#define PREMVOS_OUT_PIXSHUF2 1 /* column j = phase*cout_ps + co -> out[2y+phase/2][2x+phase%2][co] */
+
+const char* premvos_last_error(void);
+int premvos_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense convolution as implicit GEMM on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32),
+ * fused bias (+ folded BatchNorm) + residual add + activation, writing into a channel
+ * slice of a (concat) buffer.
+ *
+ * Replaces every dense conv call the reference makes through its frameworks:
+ *   optical_flow_net-PWC-Net/models/PWCNet.py:24-34 (conv / predict_flow / deconv builders),
+ *   proposal_net/basemodel.py:51-99 (Conv2D+BNReLU bottlenecks), proposal_net/model.py:30-51,
+ *   refinement_net/network/deeplab/core/xception.py:154-178 (pointwise halves), model.py:383-433.
+ *
+ * Weights are pre-packed by the host (premvos_amd/packing.py) as a row-major matrix
+ * wgt[cout_pad][k_pad], k = (kh*KW + kw)*cin_pad + c, cin_pad = roundup(cin,4),
+ * k_pad = roundup(KH*KW*cin_pad, 16), cout_pad = roundup(cout, 32); zero filled padding.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct premvos_conv_desc {
+  const float* in;      /* NHWC slice base */
+  const float* wgt;     /* packed weights  */
+  const float* bias;    /* [cout_pad] or NULL */
+  const float* res;     /* residual NHWC slice (same N,Ho,Wo,cout) or NULL; added before act */
+  float* out;           /* NHWC slice base */
+  int32_t n, h, w, cin; /* input dims      */
+  int32_t in_ps;        /* input pixel stride (elements) */
+  int32_t ho, wo, cout; /* output dims     */
+  int32_t out_ps;       /* output pixel stride */
+  int32_t res_ps;       /* residual pixel stride */
+  int32_t kh, kw;       /* kernel          */
+  int32_t sh, sw;       /* stride          */
+  int32_t dh, dw;       /* dilation        */
+  int32_t pt, pl;       /* pad top / left (bottom/right follow from ho,wo: asymmetric pads ok) */
+  int32_t cin_pad, k_pad, cout_pad;
+  int32_t act;          /* PREMVOS_ACT_*   */
+  float slope;          /* leaky slope     */
+  int32_t out_mode;     /* PREMVOS_OUT_*   */
+  int32_t cout_ps;      /* PIXSHUF2: channels per phase (cout == 4*cout_ps); out dims are 2ho x 2wo */
+  int32_t tile_hint;    /* 0 = auto; else (BM<<16)|BN to force a tile config (bench/tests) */
+} premvos_conv_desc;
+
+int premvos_conv2d_f32(const premvos_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PWC-Net cost volume, the only first-party native kernel of the reference:
+ *   corr_cuda_forward  correlation_package/src/corr_cuda.c:7-82
+ *   blob_rearrange_kernel2 / CorrelateData  src/corr_cuda_kernel.cu:18-37, 59-127
+ * for the instantiation PWC-Net uses (pad = max_displacement = md, kernel_size = 1,
+ * stride1 = stride2 = 1, multiply; PWCNet.py:69):
+ *   out[y][x][(dy+md)*(2md+1) + (dx+md)] = (1/C) * sum_c f1[y][x][c] * f2[y+dy][x+dx][c]
+ * (zero outside), with the LeakyReLU the reference applies right after (PWCNet.py:198)
+ * fused when `slope` != 1, written into channels [0, (2md+1)^2) of `out`; if `copy_f1`
+ * the f1 features are also copied to channels [(2md+1)^2, +C) (the torch.cat of
+ * PWCNet.py:213).  No NCHW->NHWC rearrange pass and no zeroed scratch: inputs ARE NHWC.
+ * ---------------------------------------------------------------------------------------- */
+int premvos_corr_fwd_f32(const float* f1, int32_t f1_ps, const float* f2, int32_t f2_ps, float* out,
+                         int32_t out_ps, int32_t n, int32_t h, int32_t w, int32_t c, int32_t md,
+                         float slope, int32_t copy_f1, void* stream);
+
+/* General form of the reference op signature (pad_size, kernel_size, max_displacement, stride1,
+ * stride2, corr_type_multiply) on NCHW tensors -- the exact argument list of corr_cuda_forward
+ * (corr_cuda.h:1-11) minus the THCudaTensor scratch (rbot1/rbot2 are not needed).  Supports the
+ * multiply type only (the reference's subtract path is never instantiated by PWCNet.py).
+ * out must hold n * D*D * oh * ow floats (shape math of corr_cuda.c:23-45). */
+int premvos_corr_nchw_fwd_f32(const float* in1, const float* in2, float* out, int32_t n, int32_t c,
+                              int32_t h, int32_t w, int32_t pad_size, int32_t kernel_size,
+                              int32_t max_displacement, int32_t stride1, int32_t stride2,
+                              int32_t corr_type_multiply, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward bilinear warp of image-2 features by (flow * flow_scale) times the validity mask
+ * (grid_sample(ones) >= 0.9999): PWCDCNet.warp, models/PWCNet.py:140-176, torch-0.2 grid_sample
+ * (bilinear, zeros padding, align_corners=True).  flow is NHWC with 2 channels (u,v).
+ * ---------------------------------------------------------------------------------------- */
+int premvos_warp_fwd_f32(const float* x, int32_t x_ps, const float* flow, int32_t flow_ps, float flow_scale,
+                         float* out, int32_t out_ps, int32_t n, int32_t h, int32_t w, int32_t c,
+                         void* stream);
+
+/* layout plumbing at the stage edges (the reference nets take/return NCHW) */
+int premvos_nchw_to_nhwc_f32(const float* in, float* out, int32_t out_ps, int32_t n, int32_t c, int32_t h,
+                             int32_t w, void* stream);
+int premvos_nhwc_to_nchw_f32(const float* in, int32_t in_ps, float* out, int32_t n, int32_t c, int32_t h,
+                             int32_t w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flow-stage host pre/post processing moved on-device (script_pwc_multi.py:33-70):
+ *  pre : two HWC uint8 RGB frames -> cv2.resize(INTER_LINEAR, uint8 fixed point) to (w_,h_) ->
+ *        BGR, /255 -> NHWC fp32 [2][h_][w_][4] (4th channel 0)          (:38-56)
+ *  post: flow2 NHWC [h4][w4][2] -> x20 -> cv2.resize(float INTER_LINEAR) to (w,h) -> u*=w/w_,
+ *        v*=h/h_ -> HWC [h][w][2] (the .flo payload layout)              (:59-68)
+ * ---------------------------------------------------------------------------------------- */
+int premvos_flow_preprocess_u8(const uint8_t* im1, const uint8_t* im2, int32_t h, int32_t w, float* out,
+                               int32_t h_, int32_t w_, void* stream);
+int premvos_flow_postprocess_f32(const float* flow2, int32_t h4, int32_t w4, float* out, int32_t h, int32_t w,
+                                 int32_t h_, int32_t w_, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PREMVOS_HIP_H */

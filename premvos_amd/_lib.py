@@ -1,0 +1,99 @@
+"""ctypes binding of libpremvos_hip.so -- the only way the Python host reaches the GPU kernels.
+
+There is NO fallback: if the library is missing and cannot be built (hipcc absent) every op
+raises.  torch is imported first so the library binds to the HIP runtime torch already loaded
+(same SONAME), which makes torch's stream handles valid inside the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the library)
+
+from . import build as _build
+
+_LIB = None
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+OUT_NHWC, OUT_PIXSHUF2 = 0, 1
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``premvos_conv_desc`` (include/premvos_hip.h)."""
+    _fields_ = [
+        ("inp", C.c_void_p), ("wgt", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+        ("out", C.c_void_p),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32),
+        ("in_ps", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32),
+        ("out_ps", C.c_int32), ("res_ps", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+        ("dh", C.c_int32), ("dw", C.c_int32), ("pt", C.c_int32), ("pl", C.c_int32),
+        ("cin_pad", C.c_int32), ("k_pad", C.c_int32), ("cout_pad", C.c_int32),
+        ("act", C.c_int32), ("slope", C.c_float), ("out_mode", C.c_int32), ("cout_ps", C.c_int32),
+        ("tile_hint", C.c_int32),
+    ]
+
+
+_i32, _f32, _vp = C.c_int32, C.c_float, C.c_void_p
+
+# name -> argtypes; every symbol include/premvos_hip.h declares (tests check the header against this)
+SIGNATURES = {
+    "premvos_conv2d_f32": [C.POINTER(ConvDesc), _vp],
+    "premvos_corr_fwd_f32": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "premvos_corr_nchw_fwd_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "premvos_warp_fwd_f32": [_vp, _i32, _vp, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "premvos_nchw_to_nhwc_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "premvos_nhwc_to_nchw_f32": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "premvos_flow_preprocess_u8": [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp],
+    "premvos_flow_postprocess_f32": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+}
+
+
+class PremvosError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load (building first if sources are newer and hipcc exists).  Raises if impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    try:
+        if _build.needs_build():
+            _build.build_lib()
+    except Exception as e:  # no hipcc on this box: a prebuilt .so must have travelled
+        if not os.path.exists(path):
+            raise PremvosError(
+                f"libpremvos_hip.so is missing and could not be built ({e}); the HIP path has no fallback") from e
+    lib = C.CDLL(path)
+    lib.premvos_last_error.restype = C.c_char_p
+    lib.premvos_last_error.argtypes = []
+    lib.premvos_abi_version.restype = C.c_int
+    lib.premvos_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise PremvosError(f"{what} failed ({rc}): {load().premvos_last_error().decode()}")
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise PremvosError("no GPU visible: premvos_amd runs only on the HIP path (no CPU fallback)")

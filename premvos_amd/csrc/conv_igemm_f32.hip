@@ -1,0 +1,253 @@
+// Dense convolution as implicit GEMM on the gfx950 fp32 matrix pipe.
+//
+//   M = N*Ho*Wo output pixels, Ncol = Cout, K = KH*KW*cin_pad  (k = tap*cin_pad + c)
+//   D[m][j] = act( sum_k A[m][k] * B[j][k] + bias[j] (+ res[m][j]) )
+//
+// * A (activations) is gathered straight from the NHWC input slice: one 16-byte load per
+//   (pixel, tap, 4 channels), zero filled outside the image (any asymmetric padding), staged
+//   through LDS; B (packed weights, k contiguous) likewise.  LDS rows are padded to 20 floats so
+//   the ds_read_b128 fragment reads of both operands are bank-conflict free.
+// * Math: v_mfma_f32_32x32x2_f32 -- exact fp32 (bitwise an fmaf chain in k order) at the
+//   157 TFLOP/s fp32 rate, i.e. the PWC-Net fp32 config stays fp32 end to end.
+//   One float4 LDS read feeds 4 MFMAs: lane l holds k = 4*(l>>5)+{0..3} of an 8-deep k group for
+//   row/col (l&31); MFMA e pairs k = e and k = 4+e of both operands.
+// * C/D layout (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): with M = pixels and
+//   N = cout every store instruction writes 32 consecutive output channels of one pixel
+//   (128 B runs) into the NHWC destination slice -- which may be a channel window of a DenseNet
+//   concat buffer (PWCNet.py:201-205: the 54 torch.cat copies disappear).
+// * Double-buffered LDS, one barrier per 16-deep k step, next tile's global loads in flight
+//   during the MFMAs.
+//
+// Reference call sites replaced: see include/premvos_hip.h (premvos_conv2d_f32).
+#include "common.h"
+
+namespace premvos {
+thread_local char g_err[512] = "";
+}
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+namespace {
+
+constexpr int BK = 16;           // k depth per LDS stage
+constexpr int RS = BK + 4;       // LDS row stride (floats): 80 B, keeps b128 reads conflict free
+
+template <int BM, int BN, int WM, int WN, bool PIXSHUF>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NTL = WTN / 32;
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+  constexpr int A_UNITS = BM * 4, B_UNITS = BN * 4;
+  constexpr int A_PER_T = (A_UNITS + NT - 1) / NT, B_PER_T = (B_UNITS + NT - 1) / NT;
+
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * RS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
+  const int M = p.n * p.ho * p.wo;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  // ---- per-thread gather state -------------------------------------------------------------
+  const int j4 = (tid & 3) * 4;  // this thread's float4 column inside the 16-deep stage
+  const float* rowbase[A_PER_T];
+  int iy0[A_PER_T], ix0[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int row = (tid >> 2) + i * (NT / 4);
+    const int m = m0 + row;
+    const bool ok = (row < BM) && (m < M);
+    const int mm = ok ? m : 0;
+    const int hw = p.ho * p.wo;
+    const int n = mm / hw, rem = mm - n * hw;
+    const int oy = rem / p.wo, ox = rem - oy * p.wo;
+    rowbase[i] = p.in + (long)n * p.h * p.w * p.in_ps;
+    iy0[i] = ok ? oy * p.sh - p.pt : -(1 << 28);  // invalid rows fail the bounds test below
+    ix0[i] = ox * p.sw - p.pl;
+  }
+  int kh, kw, c;
+  {
+    const int tap = j4 / p.cin_pad;
+    c = j4 - tap * p.cin_pad;
+    kh = tap / p.kw;
+    kw = tap - kh * p.kw;
+  }
+  const float* wrow[B_PER_T];
+  bool wok[B_PER_T];
+#pragma unroll
+  for (int i = 0; i < B_PER_T; ++i) {
+    const int row = (tid >> 2) + i * (NT / 4);
+    wok[i] = (row < BN) && (n0 + row < p.cout_pad);
+    wrow[i] = p.wgt + (long)(wok[i] ? n0 + row : 0) * p.k_pad + j4;
+  }
+
+  float4 ra[A_PER_T], rb[B_PER_T];
+  auto gload = [&](int kt) {
+    const bool tap_ok = kh < p.kh;
+    const int dy = kh * p.dh, dx = kw * p.dw;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+      const bool ok = tap_ok && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
+      ra[i] = ok ? *reinterpret_cast<const float4*>(rowbase[i] + ((long)iy * p.w + ix) * p.in_ps + c)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i)
+      rb[i] = wok[i] ? *reinterpret_cast<const float4*>(wrow[i] + kt * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    c += BK;
+    while (c >= p.cin_pad) {
+      c -= p.cin_pad;
+      if (++kw == p.kw) { kw = 0; ++kh; }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* a = &lds[buf][0];
+    float* b = &lds[buf][BM * RS];
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int row = (tid >> 2) + i * (NT / 4);
+      if (A_UNITS % NT == 0 || row < BM) *reinterpret_cast<float4*>(a + row * RS + j4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int row = (tid >> 2) + i * (NT / 4);
+      if (B_UNITS % NT == 0 || row < BN) *reinterpret_cast<float4*>(b + row * RS + j4) = rb[i];
+    }
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int KT = p.k_pad / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+    const float* a = &lds[buf][wm0 * RS + frag_off];
+    const float* b = &lds[buf][(BM + wn0) * RS + frag_off];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 af[MT], bf[NTL];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + residual + activation, 128-byte channel runs per pixel -------------
+#pragma unroll
+  for (int ni = 0; ni < NTL; ++ni) {
+    const int col = n0 + wn0 + ni * 32 + (lane & 31);
+    const bool colok = col < p.cout;
+    const float bv = (p.bias != nullptr && colok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + row;
+        if (!colok || m >= M) continue;
+        float v = acc[mi][ni][r] + bv;
+        if (p.res != nullptr) v += p.res[(long)m * p.res_ps + col];
+        if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == PREMVOS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+        if constexpr (PIXSHUF) {
+          const int hw = p.ho * p.wo;
+          const int n = m / hw, rem = m - n * hw;
+          const int oy = rem / p.wo, ox = rem - oy * p.wo;
+          const int phase = col / p.cout_ps, co = col - phase * p.cout_ps;
+          const long opix = ((long)n * 2 * p.ho + 2 * oy + (phase >> 1)) * (2 * p.wo) + 2 * ox + (phase & 1);
+          p.out[opix * p.out_ps + co] = v;
+        } else {
+          p.out[(long)m * p.out_ps + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
+  const int M = d.n * d.ho * d.wo;
+  dim3 grid(premvos::cdiv(M, BM), premvos::cdiv(d.cout, BN));
+  dim3 block(64 * WM * WN);
+  if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, d);
+  else
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, d);
+  return premvos::check_launch("conv_igemm_f32");
+}
+
+}  // namespace
+
+extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
+  PV_REQUIRE(dp != nullptr, "conv2d: null descriptor");
+  const premvos_conv_desc& d = *dp;
+  PV_REQUIRE(d.in && d.wgt && d.out, "conv2d: null tensor pointer");
+  PV_REQUIRE(d.n > 0 && d.h > 0 && d.w > 0 && d.cin > 0 && d.ho > 0 && d.wo > 0 && d.cout > 0,
+             "conv2d: non-positive dimension");
+  PV_REQUIRE(d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.dh > 0 && d.dw > 0, "conv2d: bad kernel geometry");
+  PV_REQUIRE(d.cin_pad == (d.cin + 3) / 4 * 4, "conv2d: cin_pad must be roundup(cin,4)");
+  PV_REQUIRE(d.k_pad % BK == 0 && d.k_pad >= d.kh * d.kw * d.cin_pad, "conv2d: bad k_pad");
+  PV_REQUIRE(d.cout_pad % 32 == 0 && d.cout_pad >= d.cout, "conv2d: bad cout_pad");
+  PV_REQUIRE(d.in_ps % 4 == 0 && d.in_ps >= d.cin_pad, "conv2d: input pixel stride must be a multiple of 4 and >= cin_pad");
+  PV_REQUIRE(premvos::aligned16(d.in) && premvos::aligned16(d.wgt), "conv2d: in/wgt must be 16-byte aligned");
+  PV_REQUIRE(d.out_ps >= (d.out_mode == PREMVOS_OUT_PIXSHUF2 ? d.cout_ps : d.cout), "conv2d: out_ps < cout");
+  PV_REQUIRE(d.res == nullptr || d.res_ps >= d.cout, "conv2d: res_ps < cout");
+  PV_REQUIRE(d.res == nullptr || d.out_mode == PREMVOS_OUT_NHWC, "conv2d: residual needs NHWC output");
+  PV_REQUIRE(d.act >= PREMVOS_ACT_NONE && d.act <= PREMVOS_ACT_LEAKY, "conv2d: bad activation");
+  if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
+    PV_REQUIRE(d.cout_ps > 0 && d.cout == 4 * d.cout_ps, "conv2d: PIXSHUF2 needs cout == 4*cout_ps");
+  else
+    PV_REQUIRE(d.out_mode == PREMVOS_OUT_NHWC, "conv2d: bad out_mode");
+  PV_REQUIRE((long)d.n * d.ho * d.wo < (1L << 31), "conv2d: too many output pixels");
+
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int M = d.n * d.ho * d.wo;
+  int bm, bn;
+  if (d.tile_hint) {
+    bm = d.tile_hint >> 16;
+    bn = d.tile_hint & 0xffff;
+  } else {
+    bn = d.cout <= 32 ? 32 : d.cout <= 64 ? 64 : d.cout <= 96 ? 96 : 128;
+    const long blocks128 = (long)premvos::cdiv(M, 128) * premvos::cdiv(d.cout, bn);
+    bm = blocks128 >= 512 ? 128 : 64;
+    if (bn == 96 && bm == 64) bn = 128;  // (64,96) is not instantiated
+  }
+  switch ((bm << 16) | bn) {
+    case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2>(d, s);
+    case (128 << 16) | 96: return launch_cfg<128, 96, 4, 1>(d, s);
+    case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2>(d, s);
+    case (128 << 16) | 32: return launch_cfg<128, 32, 4, 1>(d, s);
+    case (64 << 16) | 128: return launch_cfg<64, 128, 2, 2>(d, s);
+    case (64 << 16) | 64: return launch_cfg<64, 64, 2, 2>(d, s);
+    case (64 << 16) | 32: return launch_cfg<64, 32, 2, 1>(d, s);
+    default: return premvos::fail(PREMVOS_EINVAL, "conv2d: no tile config %dx%d", bm, bn);
+  }
+}
+
+extern "C" const char* premvos_last_error(void) { return premvos::g_err; }
+extern "C" int premvos_abi_version(void) { return 1; }

@@ -1,0 +1,209 @@
+"""Thin Python wrappers over the C-ABI: NHWC slice views, weight packing, one function per kernel.
+
+PyTorch is used for device memory and streams only; every computation below is a call into
+libpremvos_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, OUT_NHWC, OUT_PIXSHUF2, ConvDesc  # noqa: F401
+
+
+def _r(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class NHWC:
+    """A channel window [coff, coff+c) of a pixel-major fp32 buffer [n,h,w,ps]."""
+
+    __slots__ = ("buf", "n", "h", "w", "c", "ps", "coff")
+
+    def __init__(self, buf: torch.Tensor, c: Optional[int] = None, coff: int = 0):
+        assert buf.dim() == 4 and buf.dtype == torch.float32 and buf.is_contiguous()
+        self.buf = buf
+        self.n, self.h, self.w, self.ps = buf.shape
+        self.coff = coff
+        self.c = self.ps - coff if c is None else c
+        assert 0 <= coff and coff + self.c <= self.ps
+
+    @staticmethod
+    def alloc(n: int, h: int, w: int, c: int, device="cuda", ps: Optional[int] = None) -> "NHWC":
+        ps = _r(c, 4) if ps is None else ps
+        return NHWC(torch.zeros((n, h, w, ps), dtype=torch.float32, device=device), c=c)
+
+    def slice(self, coff: int, c: int) -> "NHWC":
+        return NHWC(self.buf, c=c, coff=self.coff + coff)
+
+    def images(self, n0: int, n: int) -> "NHWC":
+        return NHWC(self.buf[n0:n0 + n], c=self.c, coff=self.coff)
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + 4 * self.coff
+
+    def torch(self) -> torch.Tensor:
+        """NCHW copy (tests / debugging)."""
+        return self.buf[..., self.coff:self.coff + self.c].permute(0, 3, 1, 2).contiguous()
+
+
+@dataclass
+class PackedConv:
+    """Device-resident packed weights of one conv (see premvos_hip.h for the layout)."""
+    wgt: torch.Tensor
+    bias: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    kh: int
+    kw: int
+    cin_pad: int
+    k_pad: int
+    cout_pad: int
+    cout_ps: int = 0          # >0: transposed-conv phases (PIXSHUF2)
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
+              scale: Optional[torch.Tensor] = None) -> PackedConv:
+    """OIHW fp32 -> [cout_pad][k_pad] with k = (kh*KW+kw)*cin_pad + c.  ``scale`` (per cout)
+    folds a frozen BatchNorm's gamma/sqrt(var+eps) into the weights."""
+    w = weight.detach().to(torch.float32).cpu()
+    cout, cin, kh, kw = w.shape
+    if scale is not None:
+        w = w * scale.detach().to(torch.float32).cpu().view(-1, 1, 1, 1)
+    cin_pad, cout_pad = _r(cin, 4), _r(cout, 32)
+    k = kh * kw * cin_pad
+    k_pad = _r(k, 16)
+    p = torch.zeros((cout_pad, kh * kw, cin_pad), dtype=torch.float32)
+    p[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    full = torch.zeros((cout_pad, k_pad), dtype=torch.float32)
+    full[:, :k] = p.reshape(cout_pad, k)
+    b = None
+    if bias is not None:
+        b = torch.zeros(cout_pad, dtype=torch.float32)
+        b[:cout] = bias.detach().to(torch.float32).cpu()
+        b = b.to(device)
+    return PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
+
+
+def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda") -> PackedConv:
+    """ConvTranspose2d(k=4,s=2,p=1) weights [cin,cout,4,4] -> the equivalent 3x3 conv with
+    4*cout phase outputs (phase = 2*py+px writes out[2y+py][2x+px]).  For output row 2y+py the
+    contributing input rows are y+dy with  py=0: (dy=0,ky=1),(dy=-1,ky=3);  py=1: (dy=0,ky=2),(dy=+1,ky=0)."""
+    w = weight.detach().to(torch.float32).cpu()
+    cin, cout, kh, kw = w.shape
+    assert (kh, kw) == (4, 4)
+    taps = {0: ((0, 1), (-1, 3)), 1: ((0, 2), (1, 0))}
+    w3 = torch.zeros((4 * cout, cin, 3, 3), dtype=torch.float32)
+    for py in (0, 1):
+        for px in (0, 1):
+            ph = 2 * py + px
+            for dy, ky in taps[py]:
+                for dx, kx in taps[px]:
+                    w3[ph * cout:(ph + 1) * cout, :, dy + 1, dx + 1] = w[:, :, ky, kx].t()
+    b4 = None if bias is None else bias.detach().to(torch.float32).cpu().repeat(4)
+    pk = pack_conv(w3, b4, device)
+    pk.cout_ps = cout
+    return pk
+
+
+def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1), pad=(0, 0),
+              act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None, tile_hint: int = 0) -> ConvDesc:
+    """Build the descriptor (validated again on the C side).  ``pad`` = (top, left); the output
+    size comes from ``out`` so asymmetric bottom/right padding is implicit."""
+    assert x.c == pk.cin, (x.c, pk.cin)
+    d = ConvDesc()
+    d.inp, d.wgt = x.ptr, pk.wgt.data_ptr()
+    d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    d.res = res.ptr if res is not None else None
+    d.out = out.ptr
+    d.n, d.h, d.w, d.cin, d.in_ps = x.n, x.h, x.w, x.c, x.ps
+    if pk.cout_ps:
+        assert out.c == pk.cout_ps and out.h == 2 * x.h and out.w == 2 * x.w and out.n == x.n
+        d.ho, d.wo = x.h, x.w
+        d.out_mode, d.cout_ps = OUT_PIXSHUF2, pk.cout_ps
+    else:
+        assert out.c == pk.cout and out.n == x.n, (out.c, pk.cout)
+        d.ho, d.wo = out.h, out.w
+        d.out_mode, d.cout_ps = OUT_NHWC, 0
+    d.cout, d.out_ps = pk.cout, out.ps
+    d.res_ps = res.ps if res is not None else 0
+    d.kh, d.kw = pk.kh, pk.kw
+    d.sh, d.sw = stride
+    d.dh, d.dw = dilation
+    d.pt, d.pl = pad
+    d.cin_pad, d.k_pad, d.cout_pad = pk.cin_pad, pk.k_pad, pk.cout_pad
+    d.act, d.slope = act, slope
+    d.tile_hint = tile_hint
+    return d
+
+
+def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):
+    d = conv_desc(x, pk, out, **kw)
+    _lib.check(_lib.load().premvos_conv2d_f32(C.byref(d), _lib.current_stream()), "conv2d")
+    return out
+
+
+def run_desc(d: ConvDesc, stream: Optional[int] = None):
+    _lib.check(_lib.load().premvos_conv2d_f32(C.byref(d), _lib.current_stream() if stream is None else stream),
+               "conv2d")
+
+
+def corr(f1: NHWC, f2: NHWC, out: NHWC, md: int = 4, slope: float = 1.0, copy_f1: bool = False):
+    assert (f1.n, f1.h, f1.w, f1.c) == (f2.n, f2.h, f2.w, f2.c)
+    _lib.check(_lib.load().premvos_corr_fwd_f32(f1.ptr, f1.ps, f2.ptr, f2.ps, out.ptr, out.ps, f1.n, f1.h, f1.w,
+                                                f1.c, md, slope, int(copy_f1), _lib.current_stream()), "corr")
+    return out
+
+
+def corr_nchw(in1: torch.Tensor, in2: torch.Tensor, pad_size: int, kernel_size: int, max_displacement: int,
+              stride1: int, stride2: int, corr_multiply: int = 1) -> torch.Tensor:
+    """Op-level twin of ``corr_cuda_forward`` on NCHW tensors (allocates the output itself, like
+    the reference which resizes the caller's empty tensor, corr_cuda.c:52)."""
+    import math
+    n, c, h, w = in1.shape
+    kr = (kernel_size - 1) // 2
+    border = max_displacement + kr
+    ow = int(math.ceil((w + 2 * pad_size - 2 * border) / float(stride1)))
+    oh = int(math.ceil((h + 2 * pad_size - 2 * border) / float(stride1)))
+    dd = 2 * (max_displacement // stride2) + 1
+    out = torch.empty((n, dd * dd, oh, ow), dtype=torch.float32, device=in1.device)
+    _lib.check(_lib.load().premvos_corr_nchw_fwd_f32(
+        in1.contiguous().data_ptr(), in2.contiguous().data_ptr(), out.data_ptr(), n, c, h, w, pad_size,
+        kernel_size, max_displacement, stride1, stride2, corr_multiply, _lib.current_stream()), "corr_nchw")
+    return out
+
+
+def warp(x: NHWC, flow: NHWC, scale: float, out: NHWC):
+    assert flow.c == 2 and (x.n, x.h, x.w) == (flow.n, flow.h, flow.w)
+    _lib.check(_lib.load().premvos_warp_fwd_f32(x.ptr, x.ps, flow.ptr, flow.ps, scale, out.ptr, out.ps, x.n, x.h,
+                                                x.w, x.c, _lib.current_stream()), "warp")
+    return out
+
+
+def nchw_to_nhwc(src: torch.Tensor, out: NHWC):
+    n, c, h, w = src.shape
+    assert src.is_contiguous() and (out.n, out.h, out.w) == (n, h, w) and out.c >= c and out.coff == 0
+    _lib.check(_lib.load().premvos_nchw_to_nhwc_f32(src.data_ptr(), out.ptr, out.ps, n, c, h, w,
+                                                    _lib.current_stream()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: NHWC, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if dst is None:
+        dst = torch.empty((x.n, x.c, x.h, x.w), dtype=torch.float32, device=x.buf.device)
+    _lib.check(_lib.load().premvos_nhwc_to_nchw_f32(x.ptr, x.ps, dst.data_ptr(), x.n, x.c, x.h, x.w,
+                                                    _lib.current_stream()), "nhwc_to_nchw")
+    return dst
+
+
+def out_size(size: int, k: int, stride: int, pad_lo: int, pad_hi: int, dil: int = 1) -> int:
+    return (size + pad_lo + pad_hi - dil * (k - 1) - 1) // stride + 1
+
+
+def hw_tuple(v) -> Tuple[int, int]:
+    return (v, v) if isinstance(v, int) else tuple(v)

@@ -1,0 +1,171 @@
+"""GPU parity: every flow-path kernel through the C-ABI vs the CPU oracle / plain torch fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pwc_oracle as O  # noqa: E402
+
+
+def _ops():
+    from premvos_amd import ops
+    return ops
+
+
+def _to_nhwc(t, ops, ps=None, coff=0):
+    n, c, h, w = t.shape
+    total = (coff + c + 3) // 4 * 4 if ps is None else ps
+    buf = torch.zeros((n, h, w, total), dtype=torch.float32, device="cuda")
+    buf[..., coff:coff + c] = t.permute(0, 2, 3, 1).cuda()
+    return ops.NHWC(buf, c=c, coff=coff)
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, dil, pad(t,l,b,r), act, res
+    (2, 3, 64, 64, 16, 3, 2, 1, (1, 1, 1, 1), "leaky", False),
+    (1, 16, 33, 47, 16, 3, 1, 1, (1, 1, 1, 1), "leaky", False),
+    (1, 117, 32, 48, 128, 3, 1, 1, (1, 1, 1, 1), "leaky", False),
+    (1, 565, 16, 24, 2, 3, 1, 1, (1, 1, 1, 1), "none", True),
+    (1, 128, 20, 20, 96, 3, 1, 8, (8, 8, 8, 8), "leaky", False),
+    (1, 96, 20, 36, 64, 3, 1, 16, (16, 16, 16, 16), "leaky", False),
+    (1, 196, 8, 14, 196, 3, 1, 1, (1, 1, 1, 1), "leaky", False),
+    (1, 3, 75, 133, 64, 7, 2, 1, (2, 2, 3, 3), "relu", False),     # resnet conv0, asymmetric pad
+    (2, 64, 31, 29, 256, 1, 1, 1, (0, 0, 0, 0), "relu", True),     # bottleneck 1x1 + shortcut
+    (1, 256, 30, 30, 128, 3, 2, 1, (0, 0, 1, 1), "relu", False),   # stride-2 3x3 with pad [0,1]
+    (1, 4, 65, 65, 32, 3, 2, 1, (0, 0, 0, 0), "relu", False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_torch(case):
+    ops = _ops()
+    n, cin, h, w, cout, k, s, dil, pad, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    pt, pl, pb, pr = pad
+    xp = F.pad(x, (pl, pr, pt, pb))
+    ref = F.conv2d(xp.double(), wt.double(), b.double(), stride=s, dilation=dil)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res.double()
+    if act == "leaky":
+        ref = F.leaky_relu(ref, 0.1)
+    elif act == "relu":
+        ref = F.relu(ref)
+    xin = _to_nhwc(x, ops, coff=32, ps=(32 + cin + 3) // 4 * 4 + 8)       # a window of a wider buffer
+    out = _to_nhwc(torch.zeros(ref.shape), ops, coff=5, ps=cout + 9)
+    pk = ops.pack_conv(wt, b)
+    rr = _to_nhwc(res, ops) if res is not None else None
+    ops.conv2d(xin, pk, out, stride=(s, s), dilation=(dil, dil), pad=(pt, pl),
+               act={"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY}[act], res=rr)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().double()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+    # channels outside the destination window stay untouched (zero)
+    assert out.buf[..., :5].abs().max().item() == 0 and out.buf[..., 5 + cout:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("hint", [(128, 128), (128, 96), (128, 64), (128, 32), (64, 128), (64, 64), (64, 32)])
+def test_conv2d_every_tile_config(hint):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 40, 37, 41), generator=g)
+    wt = torch.randn((100, 40, 3, 3), generator=g) * 0.07
+    b = torch.randn((100,), generator=g)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    out = _to_nhwc(torch.zeros(ref.shape), ops)
+    ops.conv2d(_to_nhwc(x, ops), ops.pack_conv(wt, b), out, pad=(1, 1), tile_hint=(hint[0] << 16) | hint[1])
+    torch.cuda.synchronize()
+    assert (out.torch().cpu().double() - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(2, 2, 8, 14), (37, 2, 16, 12), (661, 2, 8, 8)])
+def test_deconv4x4s2_matches_torch(cin, cout, h, w):
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn((2, cin, h, w), generator=g)
+    wt = torch.randn((cin, cout, 4, 4), generator=g) * (1.0 / cin) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    ref = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
+    out = _to_nhwc(torch.zeros(ref.shape), ops, coff=3, ps=12)
+    ops.conv2d(_to_nhwc(x, ops), ops.pack_deconv4x4s2(wt, b), out, pad=(1, 1))
+    torch.cuda.synchronize()
+    assert (out.torch().cpu().double() - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("c,h,w", [(196, 8, 14), (128, 16, 28), (32, 33, 50), (4, 5, 3)])
+def test_corr_matches_oracle(c, h, w):
+    ops = _ops()
+    g = torch.Generator().manual_seed(c + h)
+    f1 = torch.randn((2, c, h, w), generator=g)
+    f2 = torch.randn((2, c, h, w), generator=g)
+    ref = F.leaky_relu(torch.from_numpy(O.correlation_np(f1.numpy(), f2.numpy())), 0.1)
+    out = ops.NHWC.alloc(2, h, w, 81 + c + 7)
+    ops.corr(_to_nhwc(f1, ops), _to_nhwc(f2, ops), out.slice(4, 81 + c), 4, 0.1, True)
+    torch.cuda.synchronize()
+    got = out.slice(4, 81).torch().cpu()
+    assert (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out.slice(4 + 81, c).torch().cpu(), f1)
+    assert out.buf[..., :4].abs().max().item() == 0
+
+
+def test_corr_reference_known_answer():
+    """test/test.py:76-77: correlation(0,1,0,1,1,1) on [[1,2],[3,4]] x [[5,6],[7,8]] = [[5,12],[21,32]];
+    :81: correlation(1,1,1,1,1,1) gives 1x9x2x2."""
+    ops = _ops()
+    a = torch.tensor([[1., 2.], [3., 4.]]).view(1, 1, 2, 2).cuda()
+    b = torch.tensor([[5., 6.], [7., 8.]]).view(1, 1, 2, 2).cuda()
+    y = ops.corr_nchw(a, b, 0, 1, 0, 1, 1, 1)
+    assert torch.equal(y.cpu().view(2, 2), torch.tensor([[5., 12.], [21., 32.]]))
+    y2 = ops.corr_nchw(a, b, 1, 1, 1, 1, 1, 1)
+    assert tuple(y2.shape) == (1, 9, 2, 2)
+    assert torch.equal(y2.cpu(), torch.from_numpy(O.correlation_np(a.cpu().numpy(), b.cpu().numpy(), 1, 1, 1, 1, 1)))
+
+
+@pytest.mark.parametrize("args", [(3, 3, 4, 1, 2), (1, 3, 2, 2, 1), (20, 1, 20, 1, 2), (4, 1, 4, 1, 1)])
+def test_corr_nchw_general_geometry(args):
+    ops = _ops()
+    pad, ks, md, s1, s2 = args
+    g = torch.Generator().manual_seed(sum(args))
+    a = torch.randn((2, 5, 24, 30), generator=g)
+    b = torch.randn((2, 5, 24, 30), generator=g)
+    ref = O.correlation_np(a.numpy(), b.numpy(), pad, ks, md, s1, s2)
+    got = ops.corr_nchw(a.cuda(), b.cuda(), pad, ks, md, s1, s2, 1).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("c,h,w,mag", [(128, 16, 28, 3.0), (32, 64, 48, 10.0), (4, 7, 9, 1.0), (64, 8, 8, 1e9)])
+def test_warp_matches_oracle(c, h, w, mag):
+    ops = _ops()
+    g = torch.Generator().manual_seed(c * h)
+    x = torch.randn((2, c, h, w), generator=g)
+    flo = torch.randn((2, 2, h, w), generator=g) * mag
+    flo[0, :, 0, 0] = 0.0                 # exact identity sample
+    flo[0, :, 1, 1] = torch.tensor([1.0, -1.0])   # integer shift
+    scale = 1.25
+    ref = O.warp(x, flo * scale)
+    out = ops.NHWC.alloc(2, h, w, c)
+    ops.warp(_to_nhwc(x, ops), _to_nhwc(flo, ops), scale, out)
+    torch.cuda.synchronize()
+    got = out.torch().cpu()
+    bad = (got - ref).abs() > 1e-5 * (1 + ref.abs())
+    # a sample landing within float rounding of the 0.9999 mask threshold / a cell edge may flip
+    assert bad.float().mean().item() < 1e-4, bad.float().mean().item()
+
+
+def test_layout_roundtrip():
+    ops = _ops()
+    x = torch.randn((3, 37, 19, 45))
+    v = ops.NHWC.alloc(3, 19, 45, 37)
+    ops.nchw_to_nhwc(x.cuda(), v)
+    back = ops.nhwc_to_nchw(v)
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x)
+    assert torch.equal(v.buf[..., :37].cpu(), x.permute(0, 2, 3, 1))
+    assert v.buf[..., 37:].abs().max().item() == 0
