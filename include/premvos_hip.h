@@ -125,15 +125,16 @@ int premvos_nhwc_to_nchw_f32(const float* in, int32_t in_ps, float* out, int32_t
 
 /* ------------------------------------------------------------------------------------------
  * Flow-stage host pre/post processing moved on-device (script_pwc_multi.py:33-70):
- *  pre : two HWC uint8 RGB frames -> cv2.resize(INTER_LINEAR, uint8 fixed point) to (w_,h_) ->
- *        BGR, /255 -> NHWC fp32 [2][h_][w_][4] (4th channel 0)          (:38-56)
- *  post: flow2 NHWC [h4][w4][2] -> x20 -> cv2.resize(float INTER_LINEAR) to (w,h) -> u*=w/w_,
- *        v*=h/h_ -> HWC [h][w][2] (the .flo payload layout)              (:59-68)
+ *  pre : `batch` pairs of HWC uint8 RGB frames (im1/im2: [batch][h][w][3]) -> cv2.resize(INTER_LINEAR,
+ *        uint8 fixed point) to (w_,h_) -> BGR, /255 -> NHWC fp32 [2*batch][h_][w_][4] (4th channel 0;
+ *        images [0,batch) = first frames, [batch,2*batch) = second frames)             (:38-56)
+ *  post: flow2 NHWC [batch][h4][w4][flow_ps] (u,v in ch 0,1) -> x20 -> cv2.resize(float INTER_LINEAR) to
+ *        (w,h) -> u*=w/w_, v*=h/h_ -> [batch][h][w][2] (the .flo payload layout)        (:59-68)
  * ---------------------------------------------------------------------------------------- */
-int premvos_flow_preprocess_u8(const uint8_t* im1, const uint8_t* im2, int32_t h, int32_t w, float* out,
-                               int32_t h_, int32_t w_, void* stream);
-int premvos_flow_postprocess_f32(const float* flow2, int32_t h4, int32_t w4, float* out, int32_t h, int32_t w,
-                                 int32_t h_, int32_t w_, void* stream);
+int premvos_flow_preprocess_u8(const uint8_t* im1, const uint8_t* im2, int32_t batch, int32_t h, int32_t w,
+                               float* out, int32_t h_, int32_t w_, void* stream);
+int premvos_flow_postprocess_f32(const float* flow2, int32_t flow_ps, int32_t batch, int32_t h4, int32_t w4,
+                                 float* out, int32_t h, int32_t w, int32_t h_, int32_t w_, void* stream);
 
 #ifdef __cplusplus
 }

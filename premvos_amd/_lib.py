@@ -46,8 +46,8 @@ SIGNATURES = {
     "premvos_warp_fwd_f32": [_vp, _i32, _vp, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "premvos_nchw_to_nhwc_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "premvos_nhwc_to_nchw_f32": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
-    "premvos_flow_preprocess_u8": [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp],
-    "premvos_flow_postprocess_f32": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "premvos_flow_preprocess_u8": [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
+    "premvos_flow_postprocess_f32": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
 }
 
 

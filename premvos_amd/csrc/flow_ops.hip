@@ -192,13 +192,13 @@ __device__ inline void cv_lin_coef(int d, double scale, int ssize, int* s0, int*
 }
 
 __global__ __launch_bounds__(256) void flow_preprocess_kernel(const uint8_t* __restrict__ im1,
-                                                              const uint8_t* __restrict__ im2, int h, int w,
-                                                              float* __restrict__ out, int h_, int w_) {
-  const long total = 2L * h_ * w_;
+                                                              const uint8_t* __restrict__ im2, int batch, int h,
+                                                              int w, float* __restrict__ out, int h_, int w_) {
+  const long total = 2L * batch * h_ * w_;
   const double sx = 1.0 / ((double)w_ / (double)w), sy = 1.0 / ((double)h_ / (double)h);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int x = idx % w_, y = (idx / w_) % h_, n = idx / ((long)w_ * h_);
-    const uint8_t* im = n ? im2 : im1;
+    const uint8_t* im = (n >= batch ? im2 : im1) + (long)(n % batch) * h * w * 3;
     int x0, x1, y0, y1;
     short a0, a1, b0, b1;
     cv_lin_coef(x, sx, w, &x0, &x1, &a0, &a1);
@@ -233,14 +233,16 @@ __device__ inline void cv_lin_coef_f(int d, double scale, int ssize, int* s0, in
   *f1 = f;
 }
 
-__global__ __launch_bounds__(256) void flow_postprocess_kernel(const float* __restrict__ flow2, int h4, int w4,
+__global__ __launch_bounds__(256) void flow_postprocess_kernel(const float* __restrict__ flow2, int ps,
+                                                               int batch, int h4, int w4,
                                                                float* __restrict__ out, int h, int w, int h_,
                                                                int w_) {
-  const long total = (long)h * w;
+  const long total = (long)batch * h * w;
   const double sx = 1.0 / ((double)w / (double)w4), sy = 1.0 / ((double)h / (double)h4);
   const float ku = (float)((double)w / (double)w_), kv = (float)((double)h / (double)h_);
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int x = idx % w, y = idx / w;
+    const int x = idx % w, y = (idx / w) % h;
+    const float* fl = flow2 + (idx / ((long)w * h)) * h4 * w4 * ps;
     int x0, x1, y0, y1;
     float fx, fy;
     cv_lin_coef_f(x, sx, w4, &x0, &x1, &fx);
@@ -248,8 +250,8 @@ __global__ __launch_bounds__(256) void flow_postprocess_kernel(const float* __re
     const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
     float r[2];
     for (int ch = 0; ch < 2; ++ch) {
-      const float s00 = flow2[((long)y0 * w4 + x0) * 2 + ch] * 20.0f, s01 = flow2[((long)y0 * w4 + x1) * 2 + ch] * 20.0f;
-      const float s10 = flow2[((long)y1 * w4 + x0) * 2 + ch] * 20.0f, s11 = flow2[((long)y1 * w4 + x1) * 2 + ch] * 20.0f;
+      const float s00 = fl[((long)y0 * w4 + x0) * ps + ch] * 20.0f, s01 = fl[((long)y0 * w4 + x1) * ps + ch] * 20.0f;
+      const float s10 = fl[((long)y1 * w4 + x0) * ps + ch] * 20.0f, s11 = fl[((long)y1 * w4 + x1) * ps + ch] * 20.0f;
       const float r0 = s00 * a0 + s01 * a1, r1 = s10 * a0 + s11 * a1;
       r[ch] = r0 * b0 + r1 * b1;
     }
@@ -339,21 +341,23 @@ extern "C" int premvos_nhwc_to_nchw_f32(const float* in, int32_t in_ps, float* o
   return premvos::check_launch("nhwc_to_nchw");
 }
 
-extern "C" int premvos_flow_preprocess_u8(const uint8_t* im1, const uint8_t* im2, int32_t h, int32_t w, float* out,
-                                          int32_t h_, int32_t w_, void* stream) {
+extern "C" int premvos_flow_preprocess_u8(const uint8_t* im1, const uint8_t* im2, int32_t batch, int32_t h, int32_t w,
+                                          float* out, int32_t h_, int32_t w_, void* stream) {
   PV_REQUIRE(im1 && im2 && out, "flow_preprocess: null pointer");
-  PV_REQUIRE(h > 0 && w > 0 && h_ > 0 && w_ > 0, "flow_preprocess: bad dims");
+  PV_REQUIRE(batch > 0 && h > 0 && w > 0 && h_ > 0 && w_ > 0, "flow_preprocess: bad dims");
   PV_REQUIRE(premvos::aligned16(out), "flow_preprocess: out must be 16-byte aligned");
-  hipLaunchKernelGGL(flow_preprocess_kernel, dim3(grid_for(2L * h_ * w_)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), im1, im2, h, w, out, h_, w_);
+  hipLaunchKernelGGL(flow_preprocess_kernel, dim3(grid_for(2L * batch * h_ * w_)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), im1, im2, batch, h, w, out, h_, w_);
   return premvos::check_launch("flow_preprocess");
 }
 
-extern "C" int premvos_flow_postprocess_f32(const float* flow2, int32_t h4, int32_t w4, float* out, int32_t h,
-                                            int32_t w, int32_t h_, int32_t w_, void* stream) {
+extern "C" int premvos_flow_postprocess_f32(const float* flow2, int32_t flow_ps, int32_t batch, int32_t h4,
+                                            int32_t w4, float* out, int32_t h, int32_t w, int32_t h_, int32_t w_,
+                                            void* stream) {
   PV_REQUIRE(flow2 && out, "flow_postprocess: null pointer");
-  PV_REQUIRE(h4 > 0 && w4 > 0 && h > 0 && w > 0 && h_ > 0 && w_ > 0, "flow_postprocess: bad dims");
-  hipLaunchKernelGGL(flow_postprocess_kernel, dim3(grid_for((long)h * w)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), flow2, h4, w4, out, h, w, h_, w_);
+  PV_REQUIRE(batch > 0 && flow_ps >= 2 && h4 > 0 && w4 > 0 && h > 0 && w > 0 && h_ > 0 && w_ > 0,
+             "flow_postprocess: bad dims");
+  hipLaunchKernelGGL(flow_postprocess_kernel, dim3(grid_for((long)batch * h * w)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), flow2, flow_ps, batch, h4, w4, out, h, w, h_, w_);
   return premvos::check_launch("flow_postprocess");
 }

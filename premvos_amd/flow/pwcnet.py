@@ -57,9 +57,16 @@ class _Plan:
             keep.append(v)
             return v
 
+        self.flops: Dict[str, float] = {}   # algorithmic FLOPs (2*MAC, true cin/cout) per conv launch
+
         def conv(x, name, out, **kw):
-            d = ops.conv_desc(x, P[name], out, **kw)
+            pk = P[name]
+            d = ops.conv_desc(x, pk, out, **kw)
             steps.append(("conv:" + name, lambda d=d: ops.run_desc(d)))
+            if pk.cout_ps:   # transposed conv k4 s2: every input pixel feeds 16 taps
+                self.flops["conv:" + name] = 2.0 * x.n * x.h * x.w * 16 * pk.cin * pk.cout_ps
+            else:
+                self.flops["conv:" + name] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
 
         # frames -> NHWC [2B,H,W,4]: images [0,B) = frame 1, [B,2B) = frame 2
         img = alloc(2 * b, h, w, 3, dev)
@@ -68,6 +75,8 @@ class _Plan:
                 src = self.x_in[i, 3 * f:3 * f + 3].unsqueeze(0)
                 dst = img.images(f * b + i, 1)
                 steps.append(("nchw_to_nhwc", lambda s=src, d=dst: ops.nchw_to_nhwc(s, d)))
+        self.n_pre = len(steps)
+        self.img = img
 
         # siamese pyramid (PWCNet.py:183-194), 2B images per launch
         feats: Dict[int, NHWC] = {}
@@ -133,27 +142,35 @@ class _Plan:
         flow2 = alloc(b, lh, lw, 2, dev)
         conv(y, "dc_conv7", flow2, pad=(1, 1), res=self.level_flow[2])
         self.flow2_nhwc = flow2
+        self.n_core_end = len(steps)
         steps.append(("nhwc_to_nchw", lambda s=flow2, d=self.flow_out: ops.nhwc_to_nchw(s, d)))
         self.steps = steps
         self.buffers = keep
         self.feats, self.xbufs = feats, xbufs
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
-    def run(self):
-        for _, fn in self.steps:
+    @property
+    def core_steps(self):
+        """The network proper: NHWC frames in ``self.img`` -> ``self.flow2_nhwc``."""
+        return self.steps[self.n_pre:self.n_core_end]
+
+    def run(self, steps=None):
+        for _, fn in (self.steps if steps is None else steps):
             fn()
 
-    def capture(self):
-        """Record the launch list into a HIP graph (launch-bound coarse levels replay as one submit)."""
+    def capture(self, steps=None) -> "torch.cuda.CUDAGraph":
+        """Record a launch list into a HIP graph (launch-bound coarse levels replay as one submit)."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.run()          # warm-up outside capture
+            self.run(steps)     # warm-up outside capture
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.run()
-        self.graph = g
+            self.run(steps)
+        if steps is None:
+            self.graph = g
+        return g
 
 
 class PWCDCNet:

@@ -66,3 +66,45 @@ def test_pwc_rejects_bad_shapes():
     net = _net(0, False)
     with pytest.raises(ValueError):
         net(torch.zeros((1, 6, 60, 64), device="cuda"))
+
+
+@pytest.mark.parametrize("h,w", [(100, 150), (128, 192), (97, 250)])
+def test_flow_stage_pre_post_and_end_to_end(h, w, tmp_path):
+    """uint8 frames -> .flo payload: bit-exact fixed-point resize, 1e-6 float resize, end-to-end flow
+    within TOL of the oracle chain (script_pwc_multi.py:33-70 restated in oracle/cv_resize_oracle.py)."""
+    from oracle import cv_resize_oracle as R
+    from premvos_amd import _lib
+    from premvos_amd.flow.driver import FlowStage, readFlowFile, writeFlowFile
+    rng = np.random.default_rng(h * w)
+    base = O.synth_frame_pair(h + (-h) % 8, w + (-w) % 8, seed=h)[0].numpy()
+    im1 = (base[:3, :h, :w].transpose(1, 2, 0) * 255).round().astype(np.uint8)
+    im2 = (base[3:, :h, :w].transpose(1, 2, 0) * 255).round().astype(np.uint8)
+    im2[::7, ::5] = rng.integers(0, 256, im2[::7, ::5].shape, dtype=np.uint8)     # hard edges for the resize
+    sd = O.synth_state_dict(2)
+    stage = FlowStage(sd, batch=2)
+    a = torch.from_numpy(np.stack([im1, im2])).cuda()
+    b = torch.from_numpy(np.stack([im2, im1])).cuda()
+    got = stage.run(a, b).cpu().numpy()
+    x0, h_, w_ = R.flow_preprocess(im1, im2)
+    # (1) preprocess kernel: bit-exact vs the restated cv2 fixed-point resize
+    img = stage.plan.img.buf.cpu().numpy()            # [4,h_,w_,4]: (im1,im2 | im2,im1)
+    ref_a = x0[0, :3].transpose(1, 2, 0)
+    ref_b = x0[0, 3:].transpose(1, 2, 0)
+    assert np.array_equal(img[0, :, :, :3], ref_a) and np.array_equal(img[2, :, :, :3], ref_b)
+    assert np.array_equal(img[1, :, :, :3], ref_b) and np.array_equal(img[3, :, :, :3], ref_a)
+    assert not img[..., 3].any()
+    # (2) postprocess kernel vs restated float resize on the GPU's own flow2
+    f2 = stage.plan.flow2_nhwc.torch().cpu().numpy()
+    for i in range(2):
+        ref_post = R.flow_postprocess(f2[i], h, w, h_, w_)
+        assert np.abs(got[i] - ref_post).max() < 1e-5 * max(1.0, np.abs(ref_post).max())
+    # (3) end to end vs the oracle chain
+    with torch.no_grad():
+        ref_f2 = O.pwc_forward(sd, torch.from_numpy(x0))[0].numpy()
+    ref = R.flow_postprocess(ref_f2, h, w, h_, w_)
+    assert np.abs(got[0] - ref).max() < TOL * max(1.0, np.abs(ref).max()) * 20
+    # (4) .flo round trip
+    fn = str(tmp_path / "t.flo")
+    writeFlowFile(fn, got[0])
+    assert np.array_equal(readFlowFile(fn), got[0])
+    assert _lib.lib_path().endswith("libpremvos_hip.so")
