@@ -136,6 +136,53 @@ int premvos_flow_preprocess_u8(const uint8_t* im1, const uint8_t* im2, int32_t b
 int premvos_flow_postprocess_f32(const float* flow2, int32_t flow_ps, int32_t batch, int32_t h4, int32_t w4,
                                  float* out, int32_t h, int32_t w, int32_t h_, int32_t w_, void* stream);
 
+/* ==========================================================================================
+ * proposal_net (class-agnostic ResNet-101-C4 Faster R-CNN, `train.py --forward`); paths relative to
+ * code/proposal_net/.  The dense convs (backbone, RPN head, conv5, FC heads as 1x1 convs) go through
+ * premvos_conv2d_f32 with the frozen BatchNorm folded into weights+bias.
+ * ========================================================================================== */
+
+/* eval.py:76-77 CustomResize (cv2.resize INTER_LINEAR on the uint8 BGR frame) + basemodel.py:12-26
+ * (x/255 - mean)/std in BGR order -> NHWC fp32 [batch][nh][nw][4] (4th channel 0). */
+int premvos_proposal_preprocess_u8(const uint8_t* img_bgr, int32_t batch, int32_t h, int32_t w, float* out,
+                                   int32_t nh, int32_t nw, void* stream);
+
+/* MaxPooling('pool0', shape=3, stride=2) after tf.pad [0,1] (basemodel.py:81-82); generic k/stride/pad. */
+int premvos_maxpool_f32(const float* in, int32_t in_ps, int32_t n, int32_t h, int32_t w, int32_t c, float* out,
+                        int32_t out_ps, int32_t ho, int32_t wo, int32_t k, int32_t stride, int32_t pt, int32_t pl,
+                        float pad_value, void* stream);
+
+/* generate_rpn_proposals (model.py:169-217) fused with the anchor field (data.py:34-74, train.py:92-105) and
+ * decode_bbox_target (model.py:113-139): per image, top-`pre_nms_topk` logits (ties -> lower index), clip to
+ * the image, drop w/h <= min_size, greedy NMS (IoU > nms_thresh suppressed, TF IoU) keeping <= post_nms_topk
+ * in descending-score order.  rpn is the NHWC output of the fused RPN 1x1 heads: logits at channel
+ * [logit_off, +na), deltas at box_off + a*4 + {tx,ty,tw,th}.  out_idx are flat anchor indices
+ * (y*fw + x)*na + a -- the 'bit-exact proposal indices' of the north star.  Unused slots: zeros / -1. */
+int premvos_rpn_proposals_f32(const float* rpn, int32_t ps, int32_t n, int32_t fh, int32_t fw, int32_t na,
+                              int32_t logit_off, int32_t box_off, const float* cell_anchors, float stride,
+                              float img_h, float img_w, int32_t pre_nms_topk, int32_t post_nms_topk,
+                              float nms_thresh, float min_size, float decode_clip, float* out_boxes,
+                              float* out_scores, int32_t* out_idx, int32_t* out_count, void* stream);
+
+/* roi_align (model.py:300-374): tf.image.crop_and_resize to (2*out_size)^2 on the remapped box, extrapolation 0,
+ * fused with the 2x2 average pool.  rois: [n_img][rois_per_img][4] x1y1x2y2 in IMAGE coordinates, scaled by
+ * spatial_scale (1/16); slots >= count[img] produce zeros.  out: NHWC [n_img*rois_per_img][out][out][c]. */
+int premvos_roi_align_f32(const float* fmap, int32_t fmap_ps, int32_t n_img, int32_t h, int32_t w, int32_t c,
+                          const float* rois, const int32_t* count, int32_t rois_per_img, float spatial_scale,
+                          int32_t out_size, float* out, int32_t out_ps, void* stream);
+
+/* GlobalAvgPooling (model.py:387,561): NHWC [n][hw][c] -> [n][c]. */
+int premvos_global_avgpool_f32(const float* in, int32_t in_ps, int32_t n, int32_t hw, int32_t c, float* out,
+                               int32_t out_ps, void* stream);
+
+/* Inference tail (train.py:275-295, model.py:438-491) for NUM_CLASS=2: softmax, decode deltas / reg weights on
+ * the proposals, clip, p > score_thresh, NMS(nms_thresh), <= max_out results by descending p.
+ * head: [n_img][rois_per_img][head_ps] with class logits at [0,2) and box deltas at [2,6). */
+int premvos_frcnn_tail_f32(const float* head, int32_t head_ps, const float* rois, const int32_t* count, int32_t n_img,
+                           int32_t rois_per_img, float img_h, float img_w, float score_thresh, float nms_thresh,
+                           int32_t max_out, float decode_clip, float rw_x, float rw_y, float rw_w, float rw_h,
+                           float* out_boxes, float* out_probs, int32_t* out_idx, int32_t* out_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,10 @@
 // mask, NCHW<->NHWC edge transposes, and the flow driver's pre/post processing.
 // Reference call sites: see include/premvos_hip.h.
 #include "common.h"
+#include "resize_cv.h"
+
+using premvos::cv_lin_coef;
+using premvos::cv_lin_coef_f;
 
 namespace {
 
@@ -179,18 +183,6 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 // to int, vertical pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2   (OpenCV imgproc
 // resize.cpp: HResizeLinear / VResizeLinear<uchar,int,short,FixedPtCast<..,22>>; third-party,
 // absent from /root/reference and from this image -> parity unpinned).
-__device__ inline void cv_lin_coef(int d, double scale, int ssize, int* s0, int* s1, short* a0, short* a1) {
-  float f = (float)(((double)d + 0.5) * scale - 0.5);
-  int s = (int)floorf(f);
-  f -= (float)s;
-  if (s < 0) { f = 0.f; s = 0; }
-  if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
-  *s0 = s;
-  *s1 = s + 1 < ssize ? s + 1 : ssize - 1;
-  *a0 = (short)__float2int_rn((1.f - f) * 2048.f);
-  *a1 = (short)__float2int_rn(f * 2048.f);
-}
-
 __global__ __launch_bounds__(256) void flow_preprocess_kernel(const uint8_t* __restrict__ im1,
                                                               const uint8_t* __restrict__ im2, int batch, int h,
                                                               int w, float* __restrict__ out, int h_, int w_) {
@@ -209,10 +201,7 @@ __global__ __launch_bounds__(256) void flow_preprocess_kernel(const uint8_t* __r
       if (h_ == h && w_ == w) {
         v = im[((long)y * w + x) * 3 + ch];  // cv2.resize to the same size is a copy
       } else {
-        const int r0 = im[((long)y0 * w + x0) * 3 + ch] * a0 + im[((long)y0 * w + x1) * 3 + ch] * a1;
-        const int r1 = im[((long)y1 * w + x0) * 3 + ch] * a0 + im[((long)y1 * w + x1) * 3 + ch] * a1;
-        v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v = v < 0 ? 0 : v > 255 ? 255 : v;
+        v = premvos::cv_resize_u8_px(im, w, 3, ch, x0, x1, y0, y1, a0, a1, b0, b1);
       }
       px[2 - ch] = (float)((double)v / 255.0);  // RGB -> BGR, 1.0*im/255.0 in double then .float()
     }
@@ -222,17 +211,6 @@ __global__ __launch_bounds__(256) void flow_preprocess_kernel(const uint8_t* __r
 }
 
 // cv2.resize(float32, INTER_LINEAR) of (20*flow2) to (w,h), then u *= w/w_, v *= h/h_.
-__device__ inline void cv_lin_coef_f(int d, double scale, int ssize, int* s0, int* s1, float* f1) {
-  float f = (float)(((double)d + 0.5) * scale - 0.5);
-  int s = (int)floorf(f);
-  f -= (float)s;
-  if (s < 0) { f = 0.f; s = 0; }
-  if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
-  *s0 = s;
-  *s1 = s + 1 < ssize ? s + 1 : ssize - 1;
-  *f1 = f;
-}
-
 __global__ __launch_bounds__(256) void flow_postprocess_kernel(const float* __restrict__ flow2, int ps,
                                                                int batch, int h4, int w4,
                                                                float* __restrict__ out, int h, int w, int h_,

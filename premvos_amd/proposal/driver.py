@@ -1,0 +1,210 @@
+"""Proposal stage driver: the counterpart of proposal_net/train.py --forward and eval.py.
+
+Reference boundary kept:
+  * ``pred = OfflinePredictor(...)``; ``pred(resized_img) -> (final_boxes, final_probs, final_labels,
+    final_posterior, second_final_labels, second_final_posterior)``        (train.py:52-62, 653-657)
+  * ``detect_one_image(img, model_func)``                                  (eval.py:61-110)
+  * ``convert_results_to_json`` -> [{"bbox": [x,y,w,h] (1 decimal), "score": (2 decimals)}]   (train.py:388-428)
+  * ``forward(pred_func, output_folder, forward_dataset)``: per-frame JSON, skip if it exists (train.py:431-522)
+  * CLI flags used by simple_run.sh:33,41: --forward --agnostic --second_head --forward_dataset --load --davis_name
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+from collections import namedtuple
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .model import (RESNET_NUM_BLOCK, RESULTS_PER_IM, TEST_POST_NMS_TOPK, ProposalNet)
+
+SHORT_EDGE_SIZE, MAX_SIZE = 800, 1333      # config.py:64-65
+
+SecondDetectionResult = namedtuple(
+    "SecondDetectionResult",
+    ["box", "score", "class_id", "posterior", "mask", "second_class_id", "second_posterior", "feature_fastrcnn_pooled"])
+
+
+def custom_resize_shape(h: int, w: int, size: int = SHORT_EDGE_SIZE, max_size: int = MAX_SIZE):
+    """CustomResize._get_augment_params (common.py:47-62)."""
+    scale = size * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = size, scale * w
+    else:
+        newh, neww = scale * h, size
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * scale, neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+class OfflinePredictor:
+    """Callable with the reference predictor's call shape: resized HWC BGR image -> tuple of numpy arrays."""
+
+    def __init__(self, net: ProposalNet):
+        self.net = net
+
+    def __call__(self, resized_img: np.ndarray):
+        img = np.ascontiguousarray(resized_img)
+        if img.dtype != np.uint8:
+            img = np.clip(np.rint(img), 0, 255).astype(np.uint8)     # the pipeline only ever feeds uint8 frames
+        t = torch.from_numpy(img).unsqueeze(0).to(self.net.device)
+        p = self.net.run_resized(t)
+        return self.net.outputs(p, 0)[:6]
+
+
+class ProposalStage:
+    """Raw uint8 BGR frames [B,H,W,3] on the device -> device-resident detections, resize fused on the GPU."""
+
+    def __init__(self, weights: Dict[str, object], batch: int = 1, device: str = "cuda",
+                 num_blocks: Sequence[int] = RESNET_NUM_BLOCK, net: Optional[ProposalNet] = None,
+                 use_graph: bool = True):
+        self.net = net if net is not None else ProposalNet(weights, num_blocks, device, use_graph=False)
+        self.batch, self.device, self.use_graph = batch, device, use_graph
+        self._shape = None
+
+    def _prepare(self, h: int, w: int):
+        if self._shape == (h, w):
+            return
+        self.nh, self.nw = custom_resize_shape(h, w)
+        self.scale = (self.nh * 1.0 / h + self.nw * 1.0 / w) / 2          # eval.py:78
+        self.plan = self.net.plan(self.batch, self.nh, self.nw)
+        self.frames = torch.empty((self.batch, h, w, 3), dtype=torch.uint8, device=self.device)
+        lib, p, b = _lib.load(), self.plan, self.batch
+
+        def pre():
+            _lib.check(lib.premvos_proposal_preprocess_u8(self.frames.data_ptr(), b, h, w, p.img.ptr, self.nh, self.nw,
+                                                          _lib.current_stream()), "proposal_preprocess")
+        self.steps = [("proposal_preprocess", pre)] + list(p.steps)
+        self.graph = p.capture(self.steps) if self.use_graph else None
+        self._shape = (h, w)
+
+    def run(self, frames_bgr: torch.Tensor):
+        """Returns the plan (final_boxes [B,20,4] in RESIZED-image coordinates, final_probs, final_count ...)."""
+        assert frames_bgr.dtype == torch.uint8 and frames_bgr.shape[0] == self.batch
+        self._prepare(frames_bgr.shape[1], frames_bgr.shape[2])
+        self.frames.copy_(frames_bgr)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.plan.run(self.steps)
+        return self.plan
+
+    def detections(self, i: int, orig_hw) -> List[SecondDetectionResult]:
+        boxes, probs, labels, post, sl, sp, _ = self.net.outputs(self.plan, i)
+        return _to_results(boxes, probs, labels, post, sl, sp, self.scale, orig_hw)
+
+
+def clip_boxes(boxes: np.ndarray, shape) -> np.ndarray:
+    """common.py:107-119."""
+    orig_shape = boxes.shape
+    boxes = boxes.reshape([-1, 4])
+    h, w = shape
+    boxes[:, [0, 1]] = np.maximum(boxes[:, [0, 1]], 0)
+    boxes[:, 2] = np.minimum(boxes[:, 2], w)
+    boxes[:, 3] = np.minimum(boxes[:, 3], h)
+    return boxes.reshape(orig_shape)
+
+
+def _to_results(boxes, probs, labels, posteriors, second_labels, second_posteriors, scale, orig_shape):
+    boxes = boxes / scale                      # eval.py:93
+    boxes = clip_boxes(boxes, orig_shape)      # eval.py:94
+    return [SecondDetectionResult(*a) for a in zip(boxes, probs, labels, posteriors, [None] * len(boxes),
+                                                   second_labels, second_posteriors, [None] * len(boxes))]
+
+
+def detect_one_image(img: np.ndarray, model_func) -> List[SecondDetectionResult]:
+    """eval.py:61-110.  ``img`` HWC BGR uint8.  The resize runs on the GPU (bit-exact restatement of the
+    cv2 fixed-point INTER_LINEAR) when ``model_func`` is our OfflinePredictor; a foreign callable gets a
+    host-resized image exactly like the reference."""
+    orig_shape = img.shape[:2]
+    if isinstance(model_func, OfflinePredictor):
+        stage = _stage_for(model_func.net)
+        t = torch.from_numpy(np.ascontiguousarray(img[:, :, :3])).unsqueeze(0).to(stage.device)
+        stage.run(t)
+        return stage.detections(0, orig_shape)
+    raise TypeError("model_func must be a premvos_amd OfflinePredictor")
+
+
+_STAGES: Dict[int, ProposalStage] = {}
+
+
+def _stage_for(net: ProposalNet) -> ProposalStage:
+    if id(net) not in _STAGES:
+        _STAGES[id(net)] = ProposalStage({}, batch=1, device=net.device, net=net)
+    return _STAGES[id(net)]
+
+
+def convert_results_to_json(results, img_idx=None) -> List[dict]:
+    """train.py:388-428 (MODE_MASK False in --forward: only bbox + score)."""
+    img_res = []
+    for r in results:
+        box = np.array(r.box)
+        box[2] -= box[0]
+        box[3] -= box[1]
+        img_res.append({"bbox": list(map(lambda x: float(round(x, 1)), box)), "score": float(round(r.score, 2))})
+    return img_res
+
+
+def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Optional[str] = None,
+            generic_images_folder: Optional[str] = None, generic_images_pattern: Optional[str] = None) -> int:
+    """train.py:431-522: one JSON per frame under <output>/<seq>/<frame>.json; existing files are skipped."""
+    from PIL import Image
+    if forward_dataset.lower() == "davis":
+        with open(davis_name) as f:
+            seqs = [ln.strip() for ln in f if ln.strip()]
+        imgs = []
+        for s in seqs:
+            imgs += sorted(glob.glob(s + "*"))
+    else:
+        imgs = sorted(glob.glob(os.path.join(generic_images_folder, generic_images_pattern)))
+    n = 0
+    for fn in imgs:
+        seq = fn.split("/")[-2]
+        out_dir = os.path.join(output_folder, seq)
+        os.makedirs(out_dir, exist_ok=True)
+        out_fn = os.path.join(out_dir, os.path.splitext(os.path.basename(fn))[0] + ".json")
+        if os.path.exists(out_fn):
+            continue
+        img = np.asarray(Image.open(fn).convert("RGB"))[:, :, ::-1]       # cv2.imread gives BGR (train.py:500)
+        res = convert_results_to_json(detect_one_image(np.ascontiguousarray(img), pred_func))
+        with open(out_fn, "w") as f:
+            json.dump(res, f)
+        n += 1
+    return n
+
+
+def load_weights(path: str) -> Dict[str, object]:
+    """Weight container: a torch pickle of the name->tensor dict documented in ProposalNet.  (TF tensor-bundle
+    import is a 'next' row, SURVEY 8f-3: TensorFlow is absent from the build image.)"""
+    return torch.load(path, map_location="cpu")
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--load")
+    ap.add_argument("--forward")
+    ap.add_argument("--agnostic", action="store_true")
+    ap.add_argument("--second_head", action="store_true")
+    ap.add_argument("--forward_dataset", default="DAVIS")
+    ap.add_argument("--davis_name")
+    ap.add_argument("--generic_images_folder")
+    ap.add_argument("--generic_images_pattern")
+    a = ap.parse_args(argv)
+    if not a.forward:
+        raise SystemExit("only --forward (inference) is on the hot path; training is out of scope")
+    if not a.agnostic:
+        raise SystemExit("the shipped pipeline runs --agnostic (NUM_CLASS=2)")
+    pred = OfflinePredictor(ProposalNet(load_weights(a.load)))
+    forward(pred, a.forward, a.forward_dataset, a.davis_name, a.generic_images_folder, a.generic_images_pattern)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

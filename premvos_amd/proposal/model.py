@@ -1,0 +1,264 @@
+"""proposal_net forward on MI355X: class-agnostic ResNet-101-C4 Faster R-CNN (`train.py --forward`).
+
+Reference graph: proposal_net/train.py:107-309 (Model._build_graph, inference branch) built from
+basemodel.py:29-99 and model.py:17-51,113-217,300-395,438-491,551-565.
+
+Design: one fixed launch list per resized image shape (captured into a HIP graph): NHWC activations,
+frozen BatchNorm folded into the conv weights/bias, ReLU and the residual add fused into the conv
+epilogue, RPN class+box 1x1 heads fused into one 75-channel conv (its NHWC output IS the
+fHxfWxNA(x4) layout the reference transposes to), anchors/decode/top-k/clip/NMS in ONE kernel,
+RoIAlign (crop_and_resize + avg-pool) in one kernel, the three FC heads as one 1x1 conv, the
+inference tail (softmax/decode/clip/threshold/NMS/top-k) in one kernel.  Data-dependent counts
+(<=100 RoIs, <=20 detections) stay on the device; buffers are fixed-size so the graph is static.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..ops import ACT_NONE, ACT_RELU, NHWC
+
+RESNET_NUM_BLOCK = (3, 4, 23, 3)           # config.py:61
+ANCHOR_STRIDE = 16
+ANCHOR_SIZES = (32, 64, 128, 256, 512)
+ANCHOR_RATIOS = (0.5, 1.0, 2.0)
+NUM_ANCHOR = 15
+MAX_SIZE = 1333
+BBOX_DECODE_CLIP = float(np.float32(np.log(MAX_SIZE / 16.0)))   # config.py:77
+TEST_PRE_NMS_TOPK, TEST_POST_NMS_TOPK = 1000, 100               # config.py:101,106
+RPN_PROPOSAL_NMS_THRESH, RPN_MIN_SIZE = 0.7, 0.0
+FASTRCNN_BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
+FASTRCNN_NMS_THRESH, RESULT_SCORE_THRESH, RESULTS_PER_IM = 0.5, 0.5, 20
+NUM_CLASS, SECOND_NUM_CLASS = 2, 81
+BN_EPS = 1e-5
+
+
+def cell_anchors() -> np.ndarray:
+    """The NUM_RATIO x NUM_SCALE anchors of cell (0,0): utils/generate_anchors.py:40-100 with
+    scales = sizes/stride, then x2,y2 += 1 (data.py:34-74) -> float32 [15,4]."""
+    base = ANCHOR_STRIDE
+    scales = np.array(ANCHOR_SIZES, np.float64) / base
+    out = []
+    w = h = float(base)
+    xc = yc = 0.5 * (base - 1)
+    for r in ANCHOR_RATIOS:
+        ws = np.round(np.sqrt(w * h / r))
+        hs = np.round(ws * r)
+        for s in scales:
+            sw, sh = ws * s, hs * s
+            out.append([xc - 0.5 * (sw - 1), yc - 0.5 * (sh - 1), xc + 0.5 * (sw - 1), yc + 0.5 * (sh - 1)])
+    a = np.array(out, np.float32)
+    a[:, 2:] += 1
+    return a
+
+
+def _fold_bn(bn: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    scale = bn["gamma"].double() / torch.sqrt(bn["var"].double() + BN_EPS)
+    bias = bn["beta"].double() - bn["mean"].double() * scale
+    return scale.float(), bias.float()
+
+
+class _Plan:
+    def __init__(self, net: "ProposalNet", b: int, h: int, w: int):
+        dev = net.device
+        self.b, self.h, self.w = b, h, w
+        P, lib = net.packed, _lib.load()
+        steps: List = []
+        keep: List = []
+        self.flops: Dict[str, float] = {}
+
+        def alloc(n, hh, ww, c):
+            v = NHWC.alloc(n, hh, ww, c, dev)
+            keep.append(v)
+            return v
+
+        def conv(x, name, out, uid=None, **kw):
+            pk = P[name]
+            d = ops.conv_desc(x, pk, out, **kw)
+            key = "conv:" + (uid or name)
+            steps.append((key, lambda d=d: ops.run_desc(d)))
+            self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
+
+        self.img = alloc(b, h, w, 3)
+        # conv0: pad [2,3] + 7x7 s2 VALID + BN + ReLU; pool0: pad [0,1] + 3x3 s2 VALID  (basemodel.py:79-82)
+        h0, w0 = ops.out_size(h, 7, 2, 2, 3), ops.out_size(w, 7, 2, 2, 3)
+        c0 = alloc(b, h0, w0, 64)
+        conv(self.img, "conv0", c0, stride=(2, 2), pad=(2, 2), act=ACT_RELU)
+        hp, wp = ops.out_size(h0, 3, 2, 0, 1), ops.out_size(w0, 3, 2, 0, 1)
+        x = alloc(b, hp, wp, 64)
+
+        def pool(i=c0, o=x):
+            _lib.check(lib.premvos_maxpool_f32(i.ptr, i.ps, i.n, i.h, i.w, i.c, o.ptr, o.ps, o.h, o.w, 3, 2, 0, 0,
+                                               0.0, _lib.current_stream()), "maxpool")
+        steps.append(("maxpool", pool))
+
+        def group(x: NHWC, g: int, feat: int, count: int, stride: int) -> NHWC:
+            for i in range(count):
+                p = f"group{g}/block{i}"
+                s = stride if i == 0 else 1
+                t1 = alloc(x.n, x.h, x.w, feat)
+                conv(x, p + "/conv1", t1, act=ACT_RELU)
+                if s == 2:        # pad [0,1] + VALID stride 2  (basemodel.py:54-56)
+                    ho, wo = ops.out_size(x.h, 3, 2, 0, 1), ops.out_size(x.w, 3, 2, 0, 1)
+                    t2 = alloc(x.n, ho, wo, feat)
+                    conv(t1, p + "/conv2", t2, stride=(2, 2), pad=(0, 0), act=ACT_RELU)
+                else:
+                    t2 = alloc(x.n, x.h, x.w, feat)
+                    conv(t1, p + "/conv2", t2, pad=(1, 1), act=ACT_RELU)
+                if p + "/convshortcut" in P:   # 1x1 stride s on x[:, :, :-1, :-1] == reading pixel (s*oy, s*ox)
+                    sc = alloc(x.n, t2.h, t2.w, feat * 4)
+                    conv(x, p + "/convshortcut", sc, stride=(s, s))
+                else:
+                    sc = x
+                y = alloc(x.n, t2.h, t2.w, feat * 4)
+                conv(t2, p + "/conv3", y, res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
+                x = y
+            return x
+
+        nb = net.num_blocks
+        x = group(x, 0, 64, nb[0], 1)
+        x = group(x, 1, 128, nb[1], 2)
+        fm = group(x, 2, 256, nb[2], 2)
+        self.featuremap = fm
+        fh, fw = fm.h, fm.w
+        # rpn_head (model.py:30-51): 3x3 + ReLU, then class(15) + box(60) as one 1x1 conv
+        hid = alloc(b, fh, fw, 1024)
+        conv(fm, "rpn/conv0", hid, pad=(1, 1), act=ACT_RELU)
+        self.rpn_out = alloc(b, fh, fw, 5 * NUM_ANCHOR)
+        conv(hid, "rpn/heads", self.rpn_out)
+        R = TEST_POST_NMS_TOPK
+        self.rois = torch.zeros((b, R, 4), dtype=torch.float32, device=dev)
+        self.roi_scores = torch.zeros((b, R), dtype=torch.float32, device=dev)
+        self.roi_idx = torch.zeros((b, R), dtype=torch.int32, device=dev)
+        self.roi_count = torch.zeros((b,), dtype=torch.int32, device=dev)
+        ca = net.cell_anchors_dev
+
+        def rpn(o=self.rpn_out):
+            _lib.check(lib.premvos_rpn_proposals_f32(
+                o.ptr, o.ps, b, fh, fw, NUM_ANCHOR, 0, NUM_ANCHOR, ca.data_ptr(), float(ANCHOR_STRIDE), float(h),
+                float(w), TEST_PRE_NMS_TOPK, R, RPN_PROPOSAL_NMS_THRESH, RPN_MIN_SIZE, BBOX_DECODE_CLIP,
+                self.rois.data_ptr(), self.roi_scores.data_ptr(), self.roi_idx.data_ptr(), self.roi_count.data_ptr(),
+                _lib.current_stream()), "rpn_proposals")
+        steps.append(("rpn_proposals", rpn))
+        roi = alloc(b * R, 14, 14, 1024)
+        self.roi_feat = roi
+
+        def ralign(o=roi):
+            _lib.check(lib.premvos_roi_align_f32(fm.ptr, fm.ps, b, fh, fw, 1024, self.rois.data_ptr(),
+                                                 self.roi_count.data_ptr(), R, 1.0 / ANCHOR_STRIDE, 14, o.ptr, o.ps,
+                                                 _lib.current_stream()), "roi_align")
+        steps.append(("roi_align", ralign))
+        f5 = group(roi, 3, 512, nb[3], 2)            # resnet_conv5 (basemodel.py:92-99)
+        self.feat5 = f5
+        gp = alloc(b * R, 1, 1, 2048)
+
+        def gap(i=f5, o=gp):
+            _lib.check(lib.premvos_global_avgpool_f32(i.ptr, i.ps, i.n, i.h * i.w, i.c, o.ptr, o.ps,
+                                                      _lib.current_stream()), "gap")
+        steps.append(("global_avgpool", gap))
+        nh = NUM_CLASS + 4 * (NUM_CLASS - 1) + SECOND_NUM_CLASS
+        self.head = alloc(b * R, 1, 1, nh)
+        conv(gp, "heads", self.head)
+        M = RESULTS_PER_IM
+        self.final_boxes = torch.zeros((b, M, 4), dtype=torch.float32, device=dev)
+        self.final_probs = torch.zeros((b, M), dtype=torch.float32, device=dev)
+        self.final_idx = torch.zeros((b, M), dtype=torch.int32, device=dev)
+        self.final_count = torch.zeros((b,), dtype=torch.int32, device=dev)
+
+        def tail(hd=self.head):
+            _lib.check(lib.premvos_frcnn_tail_f32(
+                hd.ptr, hd.ps, self.rois.data_ptr(), self.roi_count.data_ptr(), b, R, float(h), float(w),
+                RESULT_SCORE_THRESH, FASTRCNN_NMS_THRESH, M, BBOX_DECODE_CLIP, *FASTRCNN_BBOX_REG_WEIGHTS,
+                self.final_boxes.data_ptr(), self.final_probs.data_ptr(), self.final_idx.data_ptr(),
+                self.final_count.data_ptr(), _lib.current_stream()), "frcnn_tail")
+        steps.append(("frcnn_tail", tail))
+        self.steps, self.buffers = steps, keep
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def run(self, steps=None):
+        for _, fn in (self.steps if steps is None else steps):
+            fn()
+
+    def capture(self, steps=None):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.run(steps)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(steps)
+        if steps is None:
+            self.graph = g
+        return g
+
+
+class ProposalNet:
+    """Weights + per-shape plans.  ``weights`` uses the reference variable names with conv
+    kernels in OIHW: 'conv0/W', 'group{g}/block{i}/conv{1,2,3}/W', '.../convshortcut/W', '<conv>/bn' = dict(gamma,
+    beta, mean, var), 'rpn/{conv0,class,box}/{W,b}', 'fastrcnn/{class,box}/{W,b}', 'secondclassification/class/{W,b}'."""
+
+    def __init__(self, weights: Dict[str, object], num_blocks: Sequence[int] = RESNET_NUM_BLOCK,
+                 device: str = "cuda", use_graph: bool = True):
+        _lib.require_gpu()
+        self.device, self.use_graph, self.num_blocks = device, use_graph, tuple(num_blocks)
+        self.packed: Dict[str, ops.PackedConv] = {}
+        self._plans: Dict[tuple, _Plan] = {}
+        self.cell_anchors_dev = torch.from_numpy(cell_anchors()).to(device)
+        w = weights
+        for name in [k[:-2] for k in w if k.endswith("/W") and (k[:-2] + "/bn") in w]:
+            scale, bias = _fold_bn(w[name + "/bn"])
+            self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale)
+        self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device)
+        self.packed["rpn/heads"] = ops.pack_conv(torch.cat([w["rpn/class/W"], w["rpn/box/W"]], 0),
+                                                 torch.cat([w["rpn/class/b"], w["rpn/box/b"]], 0), device)
+        hw = torch.cat([w["fastrcnn/class/W"], w["fastrcnn/box/W"], w["secondclassification/class/W"]], 0)
+        hb = torch.cat([w["fastrcnn/class/b"], w["fastrcnn/box/b"], w["secondclassification/class/b"]], 0)
+        self.packed["heads"] = ops.pack_conv(hw.view(hw.shape[0], hw.shape[1], 1, 1), hb, device)
+
+    def plan(self, b: int, h: int, w: int) -> _Plan:
+        key = (b, h, w)
+        if key not in self._plans:
+            if h // ANCHOR_STRIDE < 2 or w // ANCHOR_STRIDE < 2:
+                raise ValueError("image too small for the stride-16 feature map")
+            p = _Plan(self, b, h, w)
+            if self.use_graph:
+                p.capture()
+            self._plans[key] = p
+        return self._plans[key]
+
+    def run_resized(self, img_bgr: torch.Tensor) -> _Plan:
+        """img_bgr: uint8 [B,h,w,3] on the device, ALREADY resized (what the reference feeds the TF graph)."""
+        b, h, w, _ = img_bgr.shape
+        p = self.plan(b, h, w)
+        _lib.check(_lib.load().premvos_proposal_preprocess_u8(img_bgr.contiguous().data_ptr(), b, h, w, p.img.ptr, h,
+                                                              w, _lib.current_stream()), "proposal_preprocess")
+        if p.graph is not None:
+            p.graph.replay()
+        else:
+            p.run()
+        return p
+
+    def outputs(self, p: _Plan, i: int = 0):
+        """Host tuple in the order of get_model_output_names() (train.py:52-62) for image i of the batch."""
+        n = int(p.final_count[i].item())
+        boxes = p.final_boxes[i, :n].cpu().numpy()
+        probs = p.final_probs[i, :n].cpu().numpy()
+        idx = p.final_idx[i, :n].cpu().numpy().astype(np.int64)
+        labels = np.ones((n,), np.int64)
+        head = p.head.buf.view(p.b, TEST_POST_NMS_TOPK, -1)[i].cpu().numpy()
+        cls = head[:, :2]
+        e = np.exp(cls - cls.max(1, keepdims=True))
+        label_probs = e / e.sum(1, keepdims=True)
+        # train.py:287-288 quirk: gathered by *category* id (always 0 here), kept for interface parity
+        final_posterior = label_probs[np.zeros((n,), np.int64)] if n else np.zeros((0, 2), np.float32)
+        sec = head[:, 6:6 + SECOND_NUM_CLASS]
+        es = np.exp(sec - sec.max(1, keepdims=True))
+        sec_probs = es / es.sum(1, keepdims=True)
+        second_final_posterior = sec_probs[np.zeros((n,), np.int64)] if n else np.zeros((0, SECOND_NUM_CLASS), np.float32)
+        second_final_labels = (final_posterior.argmax(-1) + 1) if n else np.zeros((0,), np.int64)
+        return boxes, probs, labels, final_posterior, second_final_labels, second_final_posterior, idx

@@ -1,0 +1,101 @@
+"""CPU tests of the proposal oracle + host logic (no GPU)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import proposal_oracle as P
+
+# utils/generate_anchors.py:20-38: the table in the reference's comments is the 1-based (MATLAB) form of the
+# py-faster-rcnn anchors; the Python function returns it shifted by -1 (base window (0,0,15,15)).
+REF_TABLE_1BASED = np.array([[-83, -39, 100, 56], [-175, -87, 192, 104], [-359, -183, 376, 200],
+                             [-55, -55, 72, 72], [-119, -119, 136, 136], [-247, -247, 264, 264],
+                             [-35, -79, 52, 96], [-79, -167, 96, 184], [-167, -343, 184, 360]], np.float64)
+
+
+def test_generate_anchors_known_answer():
+    assert np.array_equal(P.generate_anchors(), REF_TABLE_1BASED - 1)
+
+
+def test_cell_anchor_field():
+    ca = P.cell_anchors()
+    assert ca.shape == (15, 4) and ca.dtype == np.float32
+    # NUM_RATIO x NUM_SCALE layout (data.py:43), sqrt-areas 32..512, x2/y2 +1 => w = round-sized
+    w, h = ca[:, 2] - ca[:, 0], ca[:, 3] - ca[:, 1]
+    assert np.allclose(np.sqrt(w[5:10] * h[5:10]), [32, 64, 128, 256, 512])
+    aa = P.all_anchors(3, 4)
+    assert aa.shape == (3, 4, 15, 4)
+    assert np.array_equal(aa[2, 3] - aa[0, 0], np.tile([48, 32, 48, 32], (15, 1)))
+    from premvos_amd.proposal import cell_anchors
+    assert np.array_equal(cell_anchors(), ca)
+
+
+def test_custom_resize_shape_davis():
+    from premvos_amd.proposal import custom_resize_shape
+    for hw in ((480, 854), (1080, 1920), (480, 480), (854, 480), (100, 3000)):
+        assert custom_resize_shape(*hw) == P.custom_resize_shape(*hw)
+    assert P.custom_resize_shape(480, 854) == (749, 1333)
+    assert P.custom_resize_shape(1080, 1920) == (750, 1333)
+
+
+def test_decode_identity_and_clip():
+    a = np.array([[10, 20, 50, 80]], np.float32)
+    assert np.allclose(P.decode_bbox_target(np.zeros((1, 4), np.float32), a), a)
+    big = P.decode_bbox_target(np.array([[0, 0, 100, 100]], np.float32), a)
+    assert np.isfinite(big).all() and big[0, 2] - big[0, 0] == pytest.approx(40 * 1333 / 16, rel=1e-5)
+    assert np.array_equal(P.clip_boxes(np.array([[-5, -5, 700, 900]], np.float32), 480, 640), [[0, 0, 640, 480]])
+
+
+def test_nms_semantics():
+    boxes = np.array([[0, 0, 10, 10], [0, 0, 10, 10.5], [20, 20, 30, 30], [0, 0, 10, 10]], np.float32)
+    scores = np.array([0.9, 0.8, 0.7, 0.9], np.float32)
+    assert P.nms_tf(boxes, scores, 10, 0.7) == [0, 2]          # ties -> lower index first; IoU>0.7 suppressed
+    assert P.nms_tf(boxes, scores, 1, 0.7) == [0]
+    assert P.iou_tf(boxes[0], np.array([5, 5, 5, 9], np.float32)) == 0     # zero-area box
+    # IoU exactly at the threshold is NOT suppressed (strict >)
+    a, b = np.array([0, 0, 2, 1], np.float32), np.array([0, 0, 1, 1], np.float32)
+    assert P.iou_tf(a, b) == np.float32(0.5) and P.nms_tf(np.stack([a, b]), np.array([1, .5], np.float32), 5, 0.5) == [0, 1]
+
+
+def test_topk_tie_rule():
+    s = np.array([1, 3, 3, 2, 3, 0], np.float32)
+    assert list(P.topk_indices(s, 2)) == [1, 2] and list(P.topk_indices(s, 4)) == [1, 2, 4, 3]
+
+
+def test_roi_align_constant_and_linear_field():
+    fm = torch.ones((1, 2, 10, 12))
+    r = P.roi_align(fm, np.array([[1.0, 1.0, 9.0, 7.0]], np.float32), 14)
+    assert torch.allclose(r, torch.ones_like(r))
+    ramp = torch.arange(12, dtype=torch.float32).view(1, 1, 1, 12).expand(1, 1, 10, 12).contiguous()
+    r = P.roi_align(ramp, np.array([[2.0, 2.0, 9.0, 8.0]], np.float32), 14)
+    # bin centres of a linear field: x0 + (i+0.5)*w/14 - 0.5
+    expect = 2.0 + (np.arange(14) + 0.5) * 7.0 / 14 - 0.5
+    assert np.allclose(r[0, 0, 3].numpy(), expect, atol=1e-5)
+
+
+def test_tail_threshold_and_empty():
+    props = np.array([[0, 0, 50, 50], [100, 100, 180, 160]], np.float32)
+    cls = np.array([[2.0, -2.0], [-1.0, 3.0]], np.float32)
+    box = np.zeros((2, 1, 4), np.float32)
+    fb, fp, fl, fi = P.fastrcnn_tail(cls, box, props, 300, 300)
+    assert list(fi) == [1] and np.allclose(fb[0], props[1]) and list(fl) == [1]
+    e = P.fastrcnn_tail(np.zeros((0, 2), np.float32), np.zeros((0, 1, 4), np.float32), np.zeros((0, 4), np.float32), 9, 9)
+    assert e[0].shape == (0, 4)
+
+
+def test_results_to_json_format():
+    js = P.results_to_json(np.array([[10.26, 20.04, 110.31, 220.49]]), np.array([0.987]))
+    assert js == [{"bbox": [10.3, 20.0, 100.0, 200.4], "score": 0.99}]
+    json.dumps(js)
+    from premvos_amd.proposal.driver import SecondDetectionResult, convert_results_to_json
+    r = SecondDetectionResult(np.array([10.26, 20.04, 110.31, 220.49]), 0.987, 1, None, None, 1, None, None)
+    assert convert_results_to_json([r]) == js
+
+
+def test_small_oracle_forward_runs():
+    w = P.synth_weights(0, (1, 1, 1, 1))
+    img = np.random.default_rng(0).integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    (fb, fp, fl, fi), inter = P.model_forward(w, img, (1, 1, 1, 1), intermediates=True)
+    assert inter["featuremap"].shape == (1, 1024, 4, 6)
+    assert fb.shape[0] == fp.shape[0] <= 20 and inter["proposals"].shape[0] <= 100
