@@ -86,7 +86,7 @@ def test_tail_threshold_and_empty():
 
 def test_results_to_json_format():
     js = P.results_to_json(np.array([[10.26, 20.04, 110.31, 220.49]]), np.array([0.987]))
-    assert js == [{"bbox": [10.3, 20.0, 100.0, 200.4], "score": 0.99}]
+    assert js == [{"bbox": [10.3, 20.0, 100.0, 200.5], "score": 0.99}]
     json.dumps(js)
     from premvos_amd.proposal.driver import SecondDetectionResult, convert_results_to_json
     r = SecondDetectionResult(np.array([10.26, 20.04, 110.31, 220.49]), 0.987, 1, None, None, 1, None, None)
