@@ -183,6 +183,49 @@ int premvos_frcnn_tail_f32(const float* head, int32_t head_ps, const float* rois
                            int32_t max_out, float decode_clip, float rw_x, float rw_y, float rw_w, float rw_h,
                            float* out_boxes, float* out_probs, int32_t* out_idx, int32_t* out_count, void* stream);
 
+/* ==========================================================================================
+ * refinement_net (DeepLabv3+ / Xception-65 on 385x385 box crops); paths relative to code/refinement_net/.
+ * Pointwise / dense convs go through premvos_conv2d_f32 (BatchNorm folded, ReLU and the module's
+ * residual add fused in the epilogue).
+ * ========================================================================================== */
+
+/* Per-box network input, fusing datasets/util/BoundingBox.py:15-19 (guidance = 1 inside round(box)),
+ * datasets/Resize.py:150-193 (crop = round(box) +- 50 px clipped; image: tf.image.resize_images bilinear,
+ * guidance: resize_nearest_neighbor, both TF1-legacy coordinates), util/Normalization.py:9-21 and
+ * DeepLabV3Plus.py:12-14 + core/feature_extractor.py:114-116.  frame: uint8 RGB [h][w][3];
+ * boxes: [max_boxes][4] (y0,x0,y1,x1) floats; *count boxes are valid (rest -> zeros).
+ * out: NHWC [max_boxes][size][size][4]; crop_boxes: [max_boxes][4] int32 (y0,x0,y1,x1). */
+int premvos_refine_input_u8(const uint8_t* frame_rgb, int32_t h, int32_t w, const float* boxes_y0x0y1x1,
+                            const int32_t* count, int32_t max_boxes, int32_t size, float* out, int32_t* crop_boxes,
+                            void* stream);
+
+/* Depthwise 3x3 (+stride, +atrous) with folded BatchNorm, optional ReLU on the INPUT (the xception module's
+ * leading tf.nn.relu, core/xception.py:252-258) and on the output (exit flow / ASPP / decoder):
+ * slim.separable_conv2d(num_outputs=None) of core/xception.py:154-167 and model.py:664-707.
+ * wgt: [9][c_pad] (tap-major, BN scale folded), bias: [c_pad] or NULL. */
+int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, int32_t h, int32_t w, int32_t c,
+                          const float* wgt, const float* bias, int32_t c_pad, float* out, int32_t out_ps, int32_t ho,
+                          int32_t wo, int32_t stride, int32_t dilation, int32_t pt, int32_t pl, int32_t pre_relu,
+                          int32_t act, void* stream);
+
+/* tf.image.resize_bilinear, TF1: align_corners=1 (model.py:399-400,570-571) or 0 = legacy src = dst*in/out. */
+int premvos_resize_bilinear_f32(const float* in, int32_t in_ps, int32_t n, int32_t h, int32_t w, int32_t c, float* out,
+                                int32_t out_ps, int32_t ho, int32_t wo, int32_t align_corners, void* stream);
+
+/* [n][1][1][c] -> every pixel of [n][h][w][c-slice]: the ASPP image-level feature (model.py:396-400). */
+int premvos_broadcast_pixel_f32(const float* in, int32_t in_ps, int32_t n, int32_t c, float* out, int32_t out_ps,
+                                int32_t h, int32_t w, void* stream);
+
+/* SegmentationSoftmax eval branch (network/SegmentationOutputLayers.py:35-61,106-135) + the forwarder's
+ * conf_score (forwarding/FewShotSegmentationForwarder.py:144-148): logits [max_boxes][lh][lw][ps>=2] ->
+ * legacy-bilinear to size^2 -> softmax/argmax -> mask (nearest) and posterior (legacy bilinear) resized to the
+ * crop box and zero padded to the frame.  mask: uint8 {0,1} [max_boxes][h][w]; posterior: float or NULL;
+ * conf_score: [max_boxes] = mean over the frame of (2p-1 inside the mask, 1-2p outside), fixed-order reduction. */
+int64_t premvos_refine_output_workspace_bytes(int32_t max_boxes, int32_t size, int32_t h, int32_t w);
+int premvos_refine_output_f32(const float* logits, int32_t logits_ps, int32_t lh, int32_t lw, const int32_t* crop_boxes,
+                              const int32_t* count, int32_t max_boxes, int32_t size, int32_t h, int32_t w,
+                              uint8_t* mask, float* posterior, float* conf_score, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,12 @@ SIGNATURES = {
                                   _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "premvos_roi_align_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _i32, _vp, _i32, _vp],
     "premvos_global_avgpool_f32": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "premvos_refine_input_u8": [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
+    "premvos_dwconv3x3_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32,
+                              _i32, _i32, _i32, _i32, _vp],
+    "premvos_resize_bilinear_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "premvos_broadcast_pixel_f32": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "premvos_refine_output_f32": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "premvos_frcnn_tail_f32": [_vp, _i32, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32,
                                _f32, _vp, _vp, _vp, _vp, _vp],
 }
@@ -89,6 +95,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.premvos_refine_output_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
+    lib.premvos_refine_output_workspace_bytes.restype = C.c_int64
     _LIB = lib
     return lib
 

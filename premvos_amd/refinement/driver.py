@@ -1,0 +1,145 @@
+"""Refinement stage driver: the counterpart of refinement_net/main.py + the few-shot forwarder, and of the
+in-process API MergeTrack uses.
+
+Reference boundary kept:
+  * JSON config with '#' comment lines and typed getters (core/Config.py:5-91); keys used: image_input_dir,
+    bb_input_dir, output_dir, load, input_size_train, use_bbox_guidance  (configs/run:2-37)
+  * batch stage: for every frame JSON under bb_input_dir/<seq>/<frame>.json write output_dir/<seq>/<frame>.json
+    = same list, same order, each proposal gaining "segmentation" {"size":[H,W],"counts":str} and "conf_score"
+    (a *string*)                                           (forwarding/FewShotSegmentationForwarder.py:85-155)
+  * in-process: ``engine = refinement_net_init()``; ``do_refinement(proposals, image_fn, engine)`` mutates and
+    returns the proposal list                              (MergeTrack/refinement_net_functions.py:19-24,38-64)
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import sys
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import rle
+from .model import RefinementNet
+
+
+class Config:
+    """core/Config.py: JSON file, lines starting with '#' stripped; typed getters with defaults."""
+
+    def __init__(self, filename: str, update_config_string: str = ""):
+        lines = [ln for ln in open(filename).readlines() if not ln.strip().startswith("#")]
+        self._entries = json.loads("\n".join(lines))
+        if update_config_string:
+            self._entries.update(json.loads(update_config_string))
+
+    def has(self, key): return key in self._entries
+
+    def _get(self, key, typ, default):
+        if key in self._entries:
+            return typ(self._entries[key])
+        if default is None:
+            raise KeyError(f"missing config key {key}")
+        return default
+
+    def int(self, key, default=None): return self._get(key, int, default)
+    def float(self, key, default=None): return self._get(key, float, default)
+    def bool(self, key, default=None): return self._get(key, bool, default)
+    def string(self, key, default=None): return self._get(key, str, default)
+    def dir(self, key, default=None):
+        p = self.string(key, default)
+        return p if p.endswith("/") else p + "/"
+
+    def int_list(self, key, default=None):
+        v = self._entries.get(key, default)
+        if v is None:
+            raise KeyError(key)
+        return [int(x) for x in v]
+
+
+def _boxes_from_proposals(proposals: List[dict]) -> np.ndarray:
+    """xywh JSON box -> [y0,x0,y1,x1] (DAVISFewShotSegmentationDataset.py:55-59)."""
+    out = np.zeros((len(proposals), 4), np.float32)
+    for i, p in enumerate(proposals):
+        x0, y0, w, h = p["bbox"]
+        out[i] = [y0, x0, y0 + h, x0 + w]
+    return out
+
+
+class RefinementEngine:
+    """What MergeTrack holds as ``engine``: refines all proposals of a frame in one batched pass."""
+
+    def __init__(self, net: RefinementNet, max_boxes: int = 40):
+        self.net, self.max_boxes = net, max_boxes
+
+    def refine_frame(self, image_rgb: np.ndarray, proposals: List[dict]) -> List[dict]:
+        if not proposals:
+            return proposals
+        boxes = _boxes_from_proposals(proposals)
+        frame = torch.from_numpy(np.ascontiguousarray(image_rgb[:, :, :3])).to(self.net.device)
+        for s in range(0, len(proposals), self.max_boxes):
+            chunk = boxes[s:s + self.max_boxes]
+            P = self.max_boxes if len(proposals) > self.max_boxes else _bucket(len(chunk))
+            p = self.net.refine(frame, torch.from_numpy(chunk).to(self.net.device), max_boxes=P)
+            masks = p.mask[:len(chunk)].cpu().numpy()
+            conf = p.conf[:len(chunk)].cpu().numpy()
+            for i in range(len(chunk)):
+                proposals[s + i]["segmentation"] = rle.encode(masks[i])
+                proposals[s + i]["conf_score"] = str(conf[i])
+        return proposals
+
+
+def _bucket(n: int) -> int:
+    for b in (1, 2, 4, 8, 12, 20, 40):
+        if n <= b:
+            return b
+    return n
+
+
+def do_refinement(proposals: List[dict], image_fn: str, refinement_net: RefinementEngine) -> List[dict]:
+    """MergeTrack/refinement_net_functions.py:38-64."""
+    from PIL import Image
+    image = np.asarray(Image.open(image_fn).convert("RGB"))
+    return refinement_net.refine_frame(image, proposals)
+
+
+def load_weights(path: str) -> Dict[str, object]:
+    return torch.load(path, map_location="cpu")
+
+
+def refinement_net_init(config_path: str = "refinement_net/configs/live") -> RefinementEngine:
+    cfg = Config(config_path)
+    return RefinementEngine(RefinementNet(load_weights(cfg.string("load"))))
+
+
+def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_dir: str, output_dir: str) -> int:
+    """The batch stage: every <seq>/<frame>.json of bb_input_dir -> output_dir (same relative name)."""
+    from PIL import Image
+    n = 0
+    for jf in sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json"))):
+        rel = os.path.relpath(jf, bb_input_dir)
+        out_fn = os.path.join(output_dir, rel)
+        with open(jf) as f:
+            proposals = json.load(f)
+        img_fn = os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")
+        image = np.asarray(Image.open(img_fn).convert("RGB"))
+        proposals = engine.refine_frame(image, proposals)
+        os.makedirs(os.path.dirname(out_fn), exist_ok=True)
+        with open(out_fn, "w") as f:
+            json.dump(proposals, f)
+        n += 1
+    return n
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    argv = sys.argv[1:] if argv is None else argv
+    assert len(argv) in (1, 2), "usage: driver.py <config> [update_config_string]"
+    cfg = Config(argv[0], argv[1] if len(argv) > 1 else "")
+    engine = RefinementEngine(RefinementNet(load_weights(cfg.string("load"))))
+    forward_directory(engine, cfg.dir("image_input_dir"), cfg.dir("bb_input_dir"), cfg.dir("output_dir"))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,293 @@
+"""refinement_net forward on MI355X: DeepLabv3+ (Xception-65, OS16, ASPP 6/12/18, decoder OS4) on 385x385 crops.
+
+Reference graph: refinement_net/network/deeplab/{DeepLabV3Plus.py:6-39, model.py:200-707, core/xception.py:70-560,
+core/feature_extractor.py:90-116,202} + input pipeline datasets/{Dataset.py:48-56,141-186, Resize.py:150-193} +
+output layer network/SegmentationOutputLayers.py:35-61,106-135.
+
+Design: the reference feeds ONE box per session.run (batch 1, re-uploading the whole frame per box and
+pulling two full-frame maps back); here all boxes of a frame form one batch: one uploaded uint8 frame, crops
+cut on the GPU, one fixed launch list (HIP graph) over [P,385,385,4], masks and conf_scores left in HBM.
+BatchNorm is folded into the depthwise / pointwise weights, the module's leading ReLU is applied on the
+depthwise kernel's loads, the residual add rides the third pointwise conv's epilogue, ASPP branches and the
+decoder inputs are written straight into their concat buffers.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import _lib, ops
+from ..ops import ACT_NONE, ACT_RELU, NHWC
+
+INPUT_SIZE = 385
+EPS_BACKBONE, EPS_HEAD = 1e-3, 1e-5
+ATROUS_RATES = (6, 12, 18)
+BLOCKS = (   # scope, depth_list, skip, relu_inside, units, stride      (core/xception.py:506-551)
+    ("entry_flow/block1", (128, 128, 128), "conv", False, 1, 2),
+    ("entry_flow/block2", (256, 256, 256), "conv", False, 1, 2),
+    ("entry_flow/block3", (728, 728, 728), "conv", False, 1, 2),
+    ("middle_flow/block1", (728, 728, 728), "sum", False, 16, 1),
+    ("exit_flow/block1", (728, 1024, 1024), "conv", False, 1, 2),
+    ("exit_flow/block2", (1536, 1536, 2048), "none", True, 1, 1),
+)
+DECODER_SKIP = "entry_flow/block2/unit_1/xception_module/separable_conv2"
+
+
+def module_plan(num_middle: int = 16):
+    """(prefix, cin, depths, skip, relu_inside, stride, rate) per module with the stride->atrous switch of
+    stack_blocks_dense (core/xception.py:330-345) for output_stride 16."""
+    mods, cin, cur, rate = [], 64, 1, 1
+    for scope, depths, skip, relu_in, units, stride in BLOCKS:
+        for u in range(num_middle if scope.startswith("middle") else units):
+            name = f"{scope}/unit_{u + 1}/xception_module"
+            if cur == 8:
+                mods.append((name, cin, depths, skip, relu_in, 1, rate))
+                rate *= stride
+            else:
+                mods.append((name, cin, depths, skip, relu_in, stride, 1))
+                cur *= stride
+            cin = depths[-1]
+    return mods
+
+
+def _fold(bn: Dict[str, torch.Tensor], eps: float):
+    scale = bn["gamma"].double() / torch.sqrt(bn["var"].double() + eps)
+    return scale.float(), (bn["beta"].double() - bn["mean"].double() * scale).float()
+
+
+class PackedDW:
+    def __init__(self, w: torch.Tensor, bn: Dict[str, torch.Tensor], eps: float, device: str):
+        c = w.shape[0]
+        self.c, self.c_pad = c, (c + 3) // 4 * 4
+        scale, bias = _fold(bn, eps)
+        wk = (w.float().view(c, 9) * scale.view(c, 1)).t().contiguous()      # [9][c]
+        full = torch.zeros((9, self.c_pad), dtype=torch.float32)
+        full[:, :c] = wk
+        b = torch.zeros(self.c_pad, dtype=torch.float32)
+        b[:c] = bias
+        self.wgt, self.bias = full.to(device), b.to(device)
+
+
+class _Plan:
+    def __init__(self, net: "RefinementNet", P: int, H: int, W: int, with_posterior: bool):
+        dev, lib = net.device, _lib.load()
+        self.P, self.H, self.W = P, H, W
+        PK, DW = net.packed, net.packed_dw
+        steps: List = []
+        self.flops: Dict[str, float] = {}
+        self.dw_bytes: Dict[str, float] = {}
+        pool: Dict[tuple, List[NHWC]] = {}
+        keep: List[NHWC] = []
+
+        def alloc(n, h, w, c) -> NHWC:
+            key = (n, h, w, c)
+            if pool.get(key):
+                return pool[key].pop()
+            v = NHWC.alloc(n, h, w, c, dev)
+            keep.append(v)
+            return v
+
+        def release(v: NHWC):
+            pool.setdefault((v.n, v.h, v.w, v.c), []).append(v)
+
+        def conv(x, name, out, **kw):
+            pk = PK[name]
+            d = ops.conv_desc(x, pk, out, **kw)
+            key = f"conv:{name}"
+            steps.append((key, lambda d=d: ops.run_desc(d)))
+            self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
+
+        def dwconv(x: NHWC, name: str, out: NHWC, stride=1, rate=1, pre_relu=False, act=ACT_NONE):
+            k = DW[name]
+            assert x.c == k.c and out.c == k.c
+
+            def f(x=x, out=out, k=k):
+                _lib.check(lib.premvos_dwconv3x3_f32(x.ptr, x.ps, x.n, x.h, x.w, x.c, k.wgt.data_ptr(),
+                                                     k.bias.data_ptr(), k.c_pad, out.ptr, out.ps, out.h, out.w, stride,
+                                                     rate, rate, rate, int(pre_relu), act, _lib.current_stream()),
+                           "dwconv3x3")
+            steps.append((f"dw:{name}", f))
+            self.dw_bytes[f"dw:{name}"] = 4.0 * k.c * (x.n * x.h * x.w + out.n * out.h * out.w)
+
+        S = INPUT_SIZE
+        self.frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+        self.boxes = torch.zeros((P, 4), dtype=torch.float32, device=dev)       # y0 x0 y1 x1
+        self.count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.crops = torch.zeros((P, 4), dtype=torch.int32, device=dev)
+        self.net_in = alloc(P, S, S, 4)
+
+        def mk_input():
+            _lib.check(lib.premvos_refine_input_u8(self.frame.data_ptr(), H, W, self.boxes.data_ptr(),
+                                                   self.count.data_ptr(), P, S, self.net_in.ptr,
+                                                   self.crops.data_ptr(), _lib.current_stream()), "refine_input")
+        steps.append(("refine_input", mk_input))
+
+        # stem: conv2d_same 3x3 s2 (pad 1 + VALID) and 3x3 s1  (core/xception.py:430-433)
+        h1 = ops.out_size(S, 3, 2, 1, 1)
+        c11 = alloc(P, h1, h1, 32)
+        conv(self.net_in, "entry_flow/conv1_1", c11, stride=(2, 2), pad=(1, 1), act=ACT_RELU)
+        x = alloc(P, h1, h1, 64)
+        conv(c11, "entry_flow/conv1_2", x, pad=(1, 1), act=ACT_RELU)
+        release(c11)
+
+        skip_feat: Optional[NHWC] = None
+        for prefix, cin, depths, skip, relu_in, stride, rate in module_plan(net.num_middle):
+            inp, cur = x, x
+            act = ACT_RELU if relu_in else ACT_NONE
+            sc = None
+            if skip == "conv":
+                ho = ops.out_size(inp.h, 1, stride, 0, 0)
+                sc = alloc(P, ho, ho, depths[-1])
+                conv(inp, prefix + "/shortcut", sc, stride=(stride, stride))
+            for i, d in enumerate(depths):
+                s = stride if i == 2 else 1
+                ho = ops.out_size(cur.h, 3, s, rate, rate, rate)
+                t = alloc(P, ho, ho, cur.c)
+                dwconv(cur, f"{prefix}/separable_conv{i + 1}_depthwise", t, stride=s, rate=rate, pre_relu=not relu_in,
+                       act=act)
+                o = alloc(P, ho, ho, d)
+                res = None
+                if i == 2 and skip == "conv":
+                    res = sc
+                elif i == 2 and skip == "sum":
+                    res = inp
+                conv(t, f"{prefix}/separable_conv{i + 1}_pointwise", o, act=act, res=res)
+                release(t)
+                if cur is not inp:
+                    if f"{prefix}/separable_conv{i}" == DECODER_SKIP:
+                        skip_feat = cur          # decoder end point: keep it alive
+                    else:
+                        release(cur)
+                cur = o
+            if sc is not None:
+                release(sc)
+            release(inp)
+            x = cur
+        feat = x
+        self.xception_out = feat
+        fh = feat.h
+
+        # ASPP (model.py:383-433): [image pooling | 1x1 | 3 atrous separable] -> concat 1280 -> 1x1 256
+        cat = alloc(P, fh, fh, 1280)
+        gp = alloc(P, 1, 1, 2048)
+        steps.append(("gap", lambda i=feat, o=gp: _lib.check(lib.premvos_global_avgpool_f32(
+            i.ptr, i.ps, i.n, i.h * i.w, i.c, o.ptr, o.ps, _lib.current_stream()), "gap")))
+        ip = alloc(P, 1, 1, 256)
+        conv(gp, "image_pooling", ip, act=ACT_RELU)
+        steps.append(("broadcast", lambda i=ip, o=cat.slice(0, 256): _lib.check(lib.premvos_broadcast_pixel_f32(
+            i.ptr, i.ps, i.n, 256, o.ptr, o.ps, o.h, o.w, _lib.current_stream()), "broadcast")))
+        conv(feat, "aspp0", cat.slice(256, 256), act=ACT_RELU)
+        for i, r in enumerate(ATROUS_RATES, 1):
+            t = alloc(P, fh, fh, 2048)
+            dwconv(feat, f"aspp{i}_depthwise", t, rate=r, act=ACT_RELU)
+            conv(t, f"aspp{i}_pointwise", cat.slice(256 * (i + 1), 256), act=ACT_RELU)
+            release(t)
+        aspp = alloc(P, fh, fh, 256)
+        conv(cat, "concat_projection", aspp, act=ACT_RELU)
+        self.aspp_out = aspp
+
+        # decoder (model.py:503-598): [aspp up-sampled (align_corners) | 1x1(skip) 48] -> 2 separable convs -> logits
+        dh = int((float(S) - 1.0) * 0.25 + 1.0)                                   # scale_dimension
+        assert skip_feat is not None and skip_feat.h == dh
+        dcat = alloc(P, dh, dh, 304)
+        steps.append(("resize_aspp", lambda i=aspp, o=dcat.slice(0, 256): _lib.check(lib.premvos_resize_bilinear_f32(
+            i.ptr, i.ps, i.n, i.h, i.w, 256, o.ptr, o.ps, o.h, o.w, 1, _lib.current_stream()), "resize")))
+        conv(skip_feat, "decoder/feature_projection0", dcat.slice(256, 48), act=ACT_RELU)
+        d = dcat
+        for j in (0, 1):
+            t = alloc(P, dh, dh, d.c)
+            dwconv(d, f"decoder/decoder_conv{j}_depthwise", t, act=ACT_RELU)
+            o = alloc(P, dh, dh, 256)
+            conv(t, f"decoder/decoder_conv{j}_pointwise", o, act=ACT_RELU)
+            d = o
+        self.decoder_out = d
+        self.logits = alloc(P, dh, dh, 2)
+        conv(d, "logits/features", self.logits)
+
+        # SegmentationSoftmax eval branch + conf_score
+        self.mask = torch.zeros((P, H, W), dtype=torch.uint8, device=dev)
+        self.posterior = torch.zeros((P, H, W), dtype=torch.float32, device=dev) if with_posterior else None
+        self.conf = torch.zeros((P,), dtype=torch.float32, device=dev)
+        wsb = int(lib.premvos_refine_output_workspace_bytes(P, S, H, W))
+        self.ws = torch.zeros((wsb + 15) // 16 * 4, dtype=torch.float32, device=dev)
+
+        def out_layer(lg=self.logits):
+            _lib.check(lib.premvos_refine_output_f32(
+                lg.ptr, lg.ps, lg.h, lg.w, self.crops.data_ptr(), self.count.data_ptr(), P, S, H, W,
+                self.mask.data_ptr(), self.posterior.data_ptr() if self.posterior is not None else None,
+                self.conf.data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
+        steps.append(("refine_output", out_layer))
+        self.steps, self.buffers = steps, keep
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def run(self, steps=None):
+        for _, fn in (self.steps if steps is None else steps):
+            fn()
+
+    def capture(self, steps=None):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.run(steps)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(steps)
+        if steps is None:
+            self.graph = g
+        return g
+
+
+class RefinementNet:
+    """``weights``: slim variable scopes (backbone keys without the 'xception_65/' prefix) ->
+    '<scope>/weights' OIHW, '<scope>/depthwise_weights' [C,1,3,3], '<scope>/BatchNorm' = dict(gamma,beta,mean,var),
+    'logits/features/biases'."""
+
+    def __init__(self, weights: Dict[str, object], num_middle: int = 16, device: str = "cuda", use_graph: bool = True):
+        _lib.require_gpu()
+        self.device, self.use_graph, self.num_middle = device, use_graph, num_middle
+        self.packed: Dict[str, ops.PackedConv] = {}
+        self.packed_dw: Dict[str, PackedDW] = {}
+        self._plans: Dict[tuple, _Plan] = {}
+        head = ("image_pooling", "aspp", "concat_projection", "decoder/")
+        for k, v in weights.items():
+            scope = k.rsplit("/", 1)[0]
+            eps = EPS_HEAD if scope.startswith(head) else EPS_BACKBONE
+            if k.endswith("/depthwise_weights"):
+                self.packed_dw[scope] = PackedDW(v, weights[scope + "/BatchNorm"], eps, device)
+            elif k.endswith("/weights"):
+                if scope + "/BatchNorm" in weights:
+                    scale, bias = _fold(weights[scope + "/BatchNorm"], eps)
+                    self.packed[scope] = ops.pack_conv(v, bias, device, scale=scale)
+                else:
+                    self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device)
+
+    def plan(self, P: int, H: int, W: int, with_posterior: bool = False) -> _Plan:
+        key = (P, H, W, with_posterior)
+        if key not in self._plans:
+            p = _Plan(self, P, H, W, with_posterior)
+            if self.use_graph:
+                p.capture()
+            self._plans[key] = p
+        return self._plans[key]
+
+    def refine(self, frame_rgb: torch.Tensor, boxes_y0x0y1x1: torch.Tensor, max_boxes: Optional[int] = None,
+               with_posterior: bool = False) -> _Plan:
+        """frame uint8 [H,W,3] RGB, boxes float [n,4] (y0,x0,y1,x1).  Results stay in the returned plan:
+        ``mask`` uint8 [P,H,W], ``conf`` [P], ``posterior`` (optional), valid for the first n entries."""
+        n = boxes_y0x0y1x1.shape[0]
+        P = max_boxes or max(n, 1)
+        assert n <= P
+        H, W, _ = frame_rgb.shape
+        p = self.plan(P, H, W, with_posterior)
+        p.frame.copy_(frame_rgb)
+        p.boxes.zero_()
+        if n:
+            p.boxes[:n].copy_(boxes_y0x0y1x1)
+        p.count.fill_(n)
+        if p.graph is not None:
+            p.graph.replay()
+        else:
+            p.run()
+        return p

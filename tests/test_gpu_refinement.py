@@ -1,0 +1,159 @@
+"""GPU parity of the refinement_net path vs the CPU oracle (oracle/refinement_oracle.py).
+Tolerances: logits / posteriors within 1e-3 (north_star: 'masks within 1e-3 of reference'); masks may only differ
+where the posterior is within 1e-3 of 0.5; crop boxes and guidance exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import refinement_oracle as R  # noqa: E402
+
+
+def _libops():
+    from premvos_amd import _lib, ops
+    return _lib, ops
+
+
+@pytest.mark.parametrize("c,h,stride,rate,pre,act", [(128, 33, 1, 1, True, 0), (256, 34, 2, 1, True, 0),
+                                                      (728, 25, 1, 2, False, 1), (2048, 25, 1, 18, False, 1),
+                                                      (304, 20, 1, 1, False, 1)])
+def test_dwconv_matches_torch(c, h, stride, rate, pre, act):
+    _lib, ops = _libops()
+    from premvos_amd.refinement.model import PackedDW
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn((2, c, h, h + 3), generator=g)
+    w = torch.randn((c, 1, 3, 3), generator=g)
+    bn = {"gamma": torch.rand(c, generator=g) + 0.5, "beta": torch.randn(c, generator=g),
+          "mean": torch.randn(c, generator=g), "var": torch.rand(c, generator=g) + 0.5}
+    xin = F.relu(x) if pre else x
+    y = F.conv2d(F.pad(xin, (rate,) * 4), w, stride=stride, dilation=rate, groups=c)
+    ref = F.batch_norm(y, bn["mean"], bn["var"], bn["gamma"], bn["beta"], False, eps=1e-3)
+    if act:
+        ref = F.relu(ref)
+    k = PackedDW(w, bn, 1e-3, "cuda")
+    xi = ops.NHWC.alloc(2, h, h + 3, c)
+    xi.buf[..., :c] = x.permute(0, 2, 3, 1).cuda()
+    out = ops.NHWC.alloc(2, ref.shape[2], ref.shape[3], c)
+    _lib.check(_lib.load().premvos_dwconv3x3_f32(xi.ptr, xi.ps, 2, h, h + 3, c, k.wgt.data_ptr(), k.bias.data_ptr(),
+                                                 k.c_pad, out.ptr, out.ps, out.h, out.w, stride, rate, rate, rate,
+                                                 int(pre), act, _lib.current_stream()))
+    assert (out.torch().cpu() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("align", [0, 1])
+def test_resize_bilinear_tf_semantics(align):
+    _lib, ops = _libops()
+    x = torch.randn((2, 8, 25, 25))
+    ref = R.resize_bilinear_tf(x, 97, 97, bool(align))
+    xi = ops.NHWC.alloc(2, 25, 25, 8)
+    xi.buf[..., :8] = x.permute(0, 2, 3, 1).cuda()
+    out = ops.NHWC.alloc(2, 97, 97, 8)
+    _lib.check(_lib.load().premvos_resize_bilinear_f32(xi.ptr, xi.ps, 2, 25, 25, 8, out.ptr, out.ps, 97, 97, align,
+                                                       _lib.current_stream()))
+    assert (out.torch().cpu() - ref).abs().max().item() < 1e-5
+
+
+BOXES = [[20.4, 30.5, 90.6, 150.5], [0.0, 0.0, 119.5, 199.5], [60.5, 100.5, 61.5, 102.5], [5.0, 150.0, 118.0, 200.0]]
+
+
+def test_refine_input_matches_oracle():
+    _lib, ops = _libops()
+    img = (np.random.default_rng(0).random((120, 200, 3)) * 255).astype(np.uint8)
+    P = 6
+    out = ops.NHWC.alloc(P, 385, 385, 4)
+    crops = torch.zeros((P, 4), dtype=torch.int32, device="cuda")
+    boxes = torch.zeros((P, 4), device="cuda")
+    boxes[:len(BOXES)] = torch.tensor(BOXES)
+    cnt = torch.tensor([len(BOXES)], dtype=torch.int32, device="cuda")
+    _lib.check(_lib.load().premvos_refine_input_u8(torch.from_numpy(img).cuda().data_ptr(), 120, 200, boxes.data_ptr(),
+                                                   cnt.data_ptr(), P, 385, out.ptr, crops.data_ptr(),
+                                                   _lib.current_stream()))
+    got = out.torch().cpu()
+    for i, b in enumerate(BOXES):
+        x, crop = R.make_input(img, b)
+        ref = R.deeplab_preprocess(x)
+        assert tuple(crops[i].tolist()) == crop
+        assert (got[i, :3] - ref[0, :3]).abs().max().item() < 1e-5
+        assert torch.equal(got[i, 3], ref[0, 3])                  # guidance exactly -1/+1
+    assert got[len(BOXES):].abs().max().item() == 0
+
+
+def test_refine_output_matches_oracle():
+    _lib, ops = _libops()
+    g = torch.Generator().manual_seed(3)
+    P, H, W = 4, 120, 200
+    lg = torch.randn((P, 2, 97, 97), generator=g) * 3
+    lg = F.avg_pool2d(F.pad(lg, (2, 2, 2, 2), mode="replicate"), 5, 1) * 3     # smooth blobs
+    crops = [(0, 0, 120, 200), (10, 20, 100, 190), (50, 60, 52, 63), (0, 150, 120, 200)]
+    li = ops.NHWC.alloc(P, 97, 97, 2)
+    li.buf[..., :2] = lg.permute(0, 2, 3, 1).cuda()
+    cr = torch.tensor(crops, dtype=torch.int32, device="cuda")
+    cnt = torch.tensor([P], dtype=torch.int32, device="cuda")
+    mask = torch.zeros((P, H, W), dtype=torch.uint8, device="cuda")
+    post = torch.zeros((P, H, W), device="cuda")
+    conf = torch.zeros((P,), device="cuda")
+    lib = _lib.load()
+    ws = torch.zeros((int(lib.premvos_refine_output_workspace_bytes(P, 385, H, W)) + 3) // 4, device="cuda")
+    _lib.check(lib.premvos_refine_output_f32(li.ptr, li.ps, 97, 97, cr.data_ptr(), cnt.data_ptr(), P, 385, H, W,
+                                             mask.data_ptr(), post.data_ptr(), conf.data_ptr(), ws.data_ptr(),
+                                             _lib.current_stream()))
+    for i in range(P):
+        rm, rp = R.output_layer(lg[i:i + 1], crops[i], H, W)
+        gp = post[i].cpu().numpy()
+        gm = mask[i].cpu().numpy()
+        assert np.abs(gp - rp).max() < 1e-5
+        diff = gm != rm
+        assert not diff.any() or np.abs(rp[diff] - 0.5).max() < 1e-3
+        assert abs(float(conf[i]) - float(R.conf_score(rm, rp))) < 1e-5
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_refinement_net_end_to_end(use_graph):
+    """Reduced depth (2 middle units), all stages compared; frame 120x200, 4 boxes batched."""
+    from premvos_amd.refinement import RefinementNet
+    nm = 2
+    w = R.synth_weights(1, nm)
+    img = (np.random.default_rng(1).random((120, 200, 3)) * 255).astype(np.uint8)
+    net = RefinementNet(w, nm, use_graph=use_graph)
+    p = net.refine(torch.from_numpy(img).cuda(), torch.tensor(BOXES).cuda(), max_boxes=6, with_posterior=True)
+    for i, b in enumerate(BOXES):
+        x, crop = R.make_input(img, b)
+        inter = {}
+        with torch.no_grad():
+            lg = R.deeplab_logits(w, x, nm, inter)
+        xo = p.xception_out.torch().cpu()[i:i + 1]
+        assert (xo - inter["xception"]).abs().max().item() < 1e-3 * max(1.0, inter["xception"].abs().max().item())
+        ao = p.aspp_out.torch().cpu()[i:i + 1]
+        assert (ao - inter["aspp"]).abs().max().item() < 1e-3 * max(1.0, inter["aspp"].abs().max().item())
+        glg = p.logits.torch().cpu()[i:i + 1]
+        assert (glg - lg).abs().max().item() < 1e-3 * max(1.0, lg.abs().max().item())
+        rm, rp = R.output_layer(lg, crop, 120, 200)
+        gp, gm = p.posterior[i].cpu().numpy(), p.mask[i].cpu().numpy()
+        assert np.abs(gp - rp).max() < 1e-3
+        diff = gm != rm
+        assert not diff.any() or np.abs(rp[diff] - 0.5).max() < 2e-3
+        assert abs(float(p.conf[i]) - float(R.conf_score(rm, rp))) < 1e-3
+    assert int(p.mask[len(BOXES):].sum()) == 0
+
+
+def test_refinement_engine_json_contract(tmp_path):
+    from premvos_amd import rle
+    from premvos_amd.refinement import RefinementEngine, RefinementNet
+    nm = 1
+    w = R.synth_weights(2, nm)
+    img = (np.random.default_rng(2).random((90, 140, 3)) * 255).astype(np.uint8)
+    props = [{"bbox": [10.5, 20.0, 60.0, 40.5], "score": 0.91}, {"bbox": [70.0, 5.0, 50.0, 80.0], "score": 0.5}]
+    ref = R.refine_proposals(w, img, props, nm)
+    eng = RefinementEngine(RefinementNet(w, nm))
+    out = eng.refine_frame(img, [dict(p) for p in props])
+    json.dumps(out)
+    for a, b in zip(out, ref):
+        assert a["bbox"] == b["bbox"] and a["score"] == b["score"]
+        assert isinstance(a["conf_score"], str) and abs(float(a["conf_score"]) - float(b["conf_score"])) < 1e-3
+        assert a["segmentation"]["size"] == [90, 140]
+        ma, mb = rle.decode(a["segmentation"]), R.rle_decode(b["segmentation"])
+        assert (ma != mb).mean() < 2e-3
