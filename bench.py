@@ -4,10 +4,15 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one batch of synthetic 480x854 frames resident in HBM.
-Each rank owns its own shard of frames (no data-path collective); the per-chunk results are
-gathered to rank 0 (the merge rank) with one RCCL gather, inside the timed region.  Rank 0 prints
-ONE JSON line.  value = frames processed by all ranks / max-over-ranks wall time.
+Metric (BASELINE.json): frames/sec of (proposal + refine + flow) on 480p DAVIS-shape frames.
+A "step" = one pass of the whole per-frame hot path over a batch of B synthetic 480x854 uint8 frames that are
+resident in HBM when the clock starts:
+    PWC-Net flow of (t, t+1)  +  proposal_net with the general AND the specific weight set (simple_run.sh:28-42)
+    +  refinement_net on P = 20 boxes per frame                                  (2.42 TFLOP/frame)
+Refinement boxes are the seeded synthetic boxes SURVEY.md 8(d) prescribes (random-weight proposals are
+meaningless); the two proposal passes still run completely (100 RoIs each) inside the timed region.
+Each rank owns its own frames (no data-path collective); per step the results (flow, masks, conf, boxes) are
+gathered to rank 0 -- the merge rank -- with RCCL, inside the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -21,49 +26,113 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix/vector peak
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) = vector peak
 H, W = 480, 854              # DAVIS 480p
-H_, W_ = 512, 896            # script_pwc_multi.py:38-45 (multiples of 64)
+P_BOXES = 20                 # RESULTS_PER_IM (proposal_net/config.py:123); SURVEY 8(d)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PREMVOS_BENCH_BATCH", "4")),
-                    help="frame pairs per step per GPU")
+                    help="frames per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(iters: int):
-    """The oracle (plain-PyTorch restatement of the reference, kind='port') on the host cores."""
+def synth_frames(batch: int, rank: int):
+    """Smooth seeded noise frames + sub-pixel translated successors, uint8 RGB [B,H,W,3]."""
     from oracle import pwc_oracle as O
+    a, b = [], []
+    for i in range(batch):
+        pair = O.synth_frame_pair(H, W + 2, seed=1234 + 100 * rank + i, shift=(1.5 + 0.25 * i, -0.75))
+        fr = (pair[0, :, :, :W].permute(1, 2, 0) * 255).round().to(torch.uint8)       # [H,W,6]
+        a.append(fr[..., :3])
+        b.append(fr[..., 3:])
+    return torch.stack(a).contiguous(), torch.stack(b).contiguous()
+
+
+def synth_boxes(batch: int, rank: int) -> torch.Tensor:
+    """[B,P,4] (y0,x0,y1,x1): seeded uniform boxes with w,h in [40,400] clipped to the frame."""
+    rng = np.random.default_rng(4321 + rank)
+    wh = rng.uniform(40, 400, (batch, P_BOXES, 2))
+    wh = np.minimum(wh, [W, H])
+    xy = rng.uniform(0, 1, (batch, P_BOXES, 2)) * (np.array([W, H]) - wh)
+    return torch.tensor(np.stack([xy[..., 1], xy[..., 0], xy[..., 1] + wh[..., 1], xy[..., 0] + wh[..., 0]], -1),
+                        dtype=torch.float32)
+
+
+def cpu_baseline():
+    """The oracle (plain-PyTorch restatement of the reference: kind='port') timed on the host cores on a bounded
+    sample of the same per-frame workload, scaled to one frame."""
+    from oracle import proposal_oracle as PO
+    from oracle import pwc_oracle as O
+    from oracle import refinement_oracle as RO
     ncpu = os.cpu_count() or 1
-    cores = min(ncpu, 32)          # torch-CPU convs collapse when oversubscribed (256 threads: 131 s/pair)
+    cores = min(ncpu, 32)          # torch-CPU convs collapse when oversubscribed (256 threads: 131 s per PWC pair)
     torch.set_num_threads(cores)
-    sd = O.synth_state_dict(0)
-    x = O.synth_frame_pair(H_, W_)
-    budget, ts = 20.0, []
+    fa, fb = synth_frames(1, 0)
     with torch.no_grad():
-        t_all = time.perf_counter()
-        O.pwc_forward(sd, x)                      # warm-up
-        if time.perf_counter() - t_all > budget:  # pathological host: report the single sample
-            ts.append(time.perf_counter() - t_all)
-        while len(ts) < iters and time.perf_counter() - t_all < budget:
-            t = time.perf_counter()
-            O.pwc_forward(sd, x)
-            ts.append(time.perf_counter() - t)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{len(ts)} PWC-Net forwards at 1x6x{H_}x{W_} fp32 (oracle/pwc_oracle.py), median, "
-                      f"bounded to ~{int(budget)} s; torch {torch.__version__} CPU, {cores} of {ncpu} host threads"}
+        sd = O.synth_state_dict(0)
+        x = O.synth_frame_pair(512, 896)
+        O.pwc_forward(sd, x)
+        t = time.perf_counter(); O.pwc_forward(sd, x); t_flow = time.perf_counter() - t
+        w = PO.synth_weights(0)
+        img = np.ascontiguousarray(fa[0].numpy()[:, :, ::-1])
+        t = time.perf_counter(); PO.detect_one_image(w, img); t_prop = time.perf_counter() - t
+        rw = RO.synth_weights(0)
+        boxes = synth_boxes(1, 0)[0].numpy()
+        nb = 3
+        t = time.perf_counter()
+        for i in range(nb):
+            net_in, crop = RO.make_input(fa[0].numpy(), boxes[i])
+            RO.output_layer(RO.deeplab_logits(rw, net_in), crop, H, W)
+        t_box = (time.perf_counter() - t) / nb
+    per_frame = t_flow + 2 * t_prop + P_BOXES * t_box
+    return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 PWC-Net pair @512x896 ({t_flow:.2f} s) + 1 proposal_net pass @749x1333/100 RoIs ({t_prop:.2f} s) "
+                      f"+ {nb} refinement boxes @385x385 ({t_box:.2f} s/box), fp32 oracle/*.py on torch "
+                      f"{torch.__version__} CPU with {cores} of {ncpu} host threads; scaled to a frame as "
+                      f"flow + 2*proposal + {P_BOXES}*box = {per_frame:.1f} s"}
+
+
+def roofline(pipe, batch):
+    """Dominant kernel = conv_igemm_f32_kernel (every dense conv of the three nets).  HIP events around every one
+    of its launches of one step, on the stream they are launched on; achieved = algorithmic FLOPs / time."""
+    reps = 3
+    items = pipe.conv_steps()          # (stage, name, fn, flops_per_step)
+    tot = [0.0] * len(items)
+    for _ in range(reps):
+        evs = []
+        for _, _, fn, _ in items:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(evs):
+            tot[i] += a.elapsed_time(b) / reps
+    # refinement launches run once per frame of the batch: weight their time by the batch size
+    mult = [batch if st == "refine" else 1 for st, _, _, _ in items]
+    ms = sum(t * m for t, m in zip(tot, mult))
+    flops = sum(it[3] for it in items)
+    nl = sum(mult)
+    ach = flops / (ms * 1e-3) / 1e12
+    per_stage = {}
+    for (st, _, _, f), t, m in zip(items, tot, mult):
+        a = per_stage.setdefault(st, [0.0, 0.0])
+        a[0] += f
+        a[1] += t * m
+    return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+            "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),
+            "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
 
 
 def main():
@@ -80,31 +149,35 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    from oracle import pwc_oracle as O                      # synthetic weights/frames generator only
-    from premvos_amd.flow.driver import FlowStage
+    # oracle modules are used here ONLY as generators of synthetic weights / frames (no checkpoint, no DAVIS)
+    from oracle import proposal_oracle as PO
+    from oracle import pwc_oracle as O
+    from oracle import refinement_oracle as RO
+    from premvos_amd.pipeline import FramePipeline
 
-    stage = FlowStage(O.synth_state_dict(0), batch=a.batch, device=str(dev))
-    # synthetic uint8 frames of DAVIS shape, resident in HBM before the clock starts
-    g = torch.Generator().manual_seed(1234 + rank)
-    pair = O.synth_frame_pair(H, W - W % 2, seed=1234 + rank)   # smooth field + sub-pixel motion
-    fr = torch.zeros((2, H, W, 3), dtype=torch.uint8)
-    for f in range(2):
-        img = (pair[0, 3 * f:3 * f + 3].permute(1, 2, 0) * 255).round().to(torch.uint8)
-        fr[f, :, :img.shape[1]] = img
-        fr[f, :, img.shape[1]:] = img[:, -1:]
-    frames1 = fr[0].unsqueeze(0).repeat(a.batch, 1, 1, 1).contiguous().to(dev)
-    frames2 = fr[1].unsqueeze(0).repeat(a.batch, 1, 1, 1).contiguous().to(dev)
-    del g
+    B = a.batch
+    pipe = FramePipeline(O.synth_state_dict(0), PO.synth_weights(0), PO.synth_weights(1), RO.synth_weights(0),
+                         batch=B, device=str(dev), boxes_per_frame=P_BOXES)
+    fa, fb = synth_frames(B, rank)
+    fa, fb = fa.to(dev), fb.to(dev)
+    boxes = synth_boxes(B, rank).to(dev)
 
-    gather_buf = None
+    gbuf = None
     if world > 1 and rank == 0:
-        gather_buf = [torch.empty((a.batch, H, W, 2), dtype=torch.float32, device=dev) for _ in range(world)]
+        gbuf = {"flow": [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(world)],
+                "masks": [torch.empty((B, P_BOXES, H, W), dtype=torch.uint8, device=dev) for _ in range(world)],
+                "small": [torch.empty((B, 2 * 20 * 5 + P_BOXES + 2), dtype=torch.float32, device=dev) for _ in range(world)]}
 
     def step():
-        flo = stage.run(frames1, frames2)                  # [B,H,W,2] fp32, the .flo payloads
-        if world > 1:
-            dist.gather(flo, gather_buf, dst=0)
-        return flo
+        r = pipe.step(fa, fb, boxes)
+        if world > 1:       # the single exchange of the path: results -> merge rank
+            small = torch.cat([r["general_boxes"].reshape(B, -1), r["general_probs"], r["specific_boxes"].reshape(B, -1),
+                               r["specific_probs"], r["conf"], r["general_count"].view(B, 1).float(),
+                               r["specific_count"].view(B, 1).float()], 1).contiguous()
+            dist.gather(r["flow"], gbuf["flow"] if rank == 0 else None, dst=0)
+            dist.gather(r["masks"], gbuf["masks"] if rank == 0 else None, dst=0)
+            dist.gather(small, gbuf["small"] if rank == 0 else None, dst=0)
+        return r
 
     for _ in range(a.warmup):
         step()
@@ -124,22 +197,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    frames = a.steps * a.batch * world
+    frames = a.steps * B * world
     out = {
         "metric": "frames/sec (proposal+refine+flow) on 480p DAVIS frames",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: PWC-Net flow on synthetic 480x854 frame pairs "
-                               f"(resized to {H_}x{W_}), fp32, uint8 frames in HBM -> .flo payload in HBM; "
-                               "proposal/refinement stages not yet in the timed path (round 1)",
-                   "pairs_per_step_per_gpu": a.batch, "stages": ["flow"],
-                   "parallelism": f"frames sharded over {world} GPU(s), one RCCL gather per step to rank 0"},
+        "config": {"workload": "configs[3] on one node: full per-frame pipe on synthetic DAVIS-shape 480x854 uint8 frames in "
+                               "HBM: PWC-Net flow (512x896) + proposal_net x2 weight sets (749x1333, ResNet-101-C4, 100 RoIs) "
+                               f"+ refinement_net (Xception-65 DeepLabv3+, {P_BOXES} seeded boxes/frame @385x385); all fp32; "
+                               "results (flow, masks, conf, boxes) left in HBM",
+                   "frames_per_step_per_gpu": B, "stages": ["flow", "proposal_general", "proposal_specific", "refinement"],
+                   "gflop_per_frame": 2420,
+                   "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of results to rank 0 per step"},
     }
     if rank == 0:
-        out["roofline"] = stage.roofline(frames1, frames2, PEAK_F32_TFLOPS)
+        if not a.no_roofline:
+            out["roofline"] = roofline(pipe, B)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

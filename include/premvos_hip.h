@@ -143,9 +143,10 @@ int premvos_flow_postprocess_f32(const float* flow2, int32_t flow_ps, int32_t ba
  * ========================================================================================== */
 
 /* eval.py:76-77 CustomResize (cv2.resize INTER_LINEAR on the uint8 BGR frame) + basemodel.py:12-26
- * (x/255 - mean)/std in BGR order -> NHWC fp32 [batch][nh][nw][4] (4th channel 0). */
+ * (x/255 - mean)/std in BGR order -> NHWC fp32 [batch][nh][nw][4] (4th channel 0).  src_is_rgb != 0: the
+ * source frame is RGB (as the flow / refinement stages read it) and is channel-swapped on load. */
 int premvos_proposal_preprocess_u8(const uint8_t* img_bgr, int32_t batch, int32_t h, int32_t w, float* out,
-                                   int32_t nh, int32_t nw, void* stream);
+                                   int32_t nh, int32_t nw, int32_t src_is_rgb, void* stream);
 
 /* MaxPooling('pool0', shape=3, stride=2) after tf.pad [0,1] (basemodel.py:81-82); generic k/stride/pad. */
 int premvos_maxpool_f32(const float* in, int32_t in_ps, int32_t n, int32_t h, int32_t w, int32_t c, float* out,

@@ -48,7 +48,7 @@ SIGNATURES = {
     "premvos_nhwc_to_nchw_f32": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "premvos_flow_preprocess_u8": [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "premvos_flow_postprocess_f32": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
-    "premvos_proposal_preprocess_u8": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
+    "premvos_proposal_preprocess_u8": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "premvos_maxpool_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "premvos_rpn_proposals_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _f32, _f32, _i32, _i32,
                                   _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],

@@ -16,7 +16,8 @@ namespace {
 // eval.py:76-77 CustomResize (cv2 INTER_LINEAR on uint8 BGR) + basemodel.py:12-26 normalisation,
 // written as NHWC fp32 with a zero 4th channel.
 __global__ __launch_bounds__(256) void proposal_preprocess_kernel(const uint8_t* __restrict__ img, int batch, int h,
-                                                                  int w, float* __restrict__ out, int nh, int nw) {
+                                                                  int w, float* __restrict__ out, int nh, int nw,
+                                                                  int src_is_rgb) {
   const long total = (long)batch * nh * nw;
   const double sx = 1.0 / ((double)nw / (double)w), sy = 1.0 / ((double)nh / (double)h);
   const float mean[3] = {0.406f, 0.456f, 0.485f};   // BGR order (basemodel.py:20-22)
@@ -30,9 +31,10 @@ __global__ __launch_bounds__(256) void proposal_preprocess_kernel(const uint8_t*
     premvos::cv_lin_coef(x, sx, w, &x0, &x1, &a0, &a1);
     premvos::cv_lin_coef(y, sy, h, &y0, &y1, &b0, &b1);
     float px[4];
-    for (int ch = 0; ch < 3; ++ch) {
-      const int v = (nh == h && nw == w) ? im[((long)y * w + x) * 3 + ch]
-                                         : premvos::cv_resize_u8_px(im, w, 3, ch, x0, x1, y0, y1, a0, a1, b0, b1);
+    for (int ch = 0; ch < 3; ++ch) {   // ch indexes the BGR order the net sees
+      const int sc = src_is_rgb ? 2 - ch : ch;
+      const int v = (nh == h && nw == w) ? im[((long)y * w + x) * 3 + sc]
+                                         : premvos::cv_resize_u8_px(im, w, 3, sc, x0, x1, y0, y1, a0, a1, b0, b1);
       px[ch] = ((float)v * inv255 - mean[ch]) / stdv[ch];
     }
     px[3] = 0.f;
@@ -463,12 +465,12 @@ inline int grid_for(long total, int per_block = 256, int cap = 256 * 16) {
 }  // namespace
 
 extern "C" int premvos_proposal_preprocess_u8(const uint8_t* img_bgr, int32_t batch, int32_t h, int32_t w, float* out,
-                                              int32_t nh, int32_t nw, void* stream) {
+                                              int32_t nh, int32_t nw, int32_t src_is_rgb, void* stream) {
   PV_REQUIRE(img_bgr && out, "proposal_preprocess: null pointer");
   PV_REQUIRE(batch > 0 && h > 0 && w > 0 && nh > 0 && nw > 0, "proposal_preprocess: bad dims");
   PV_REQUIRE(premvos::aligned16(out), "proposal_preprocess: out must be 16-byte aligned");
   hipLaunchKernelGGL(proposal_preprocess_kernel, dim3(grid_for((long)batch * nh * nw)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), img_bgr, batch, h, w, out, nh, nw);
+                     static_cast<hipStream_t>(stream), img_bgr, batch, h, w, out, nh, nw, src_is_rgb);
   return premvos::check_launch("proposal_preprocess");
 }
 

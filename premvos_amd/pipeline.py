@@ -1,0 +1,60 @@
+"""The per-frame hot path as one object: PWC-Net flow + proposal_net (general and specific weight sets,
+simple_run.sh:28-42) + refinement_net on the frame's boxes, uint8 frames in HBM -> results in HBM.
+
+Stage outputs keep the reference's interchange semantics (they become .flo / proposal JSON / refined JSON
+through the stage drivers); here they stay on the device so a rank can hand them to the merge rank with one
+gather (premvos_amd.parallel).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .flow.driver import FlowStage
+from .proposal.driver import ProposalStage
+from .proposal.model import RESNET_NUM_BLOCK, RESULTS_PER_IM
+from .refinement.model import RefinementNet
+
+
+class FramePipeline:
+    def __init__(self, flow_sd: Dict[str, torch.Tensor], prop_general: Dict[str, object],
+                 prop_specific: Dict[str, object], refine_w: Dict[str, object], batch: int = 1,
+                 device: str = "cuda", boxes_per_frame: int = RESULTS_PER_IM,
+                 num_blocks: Sequence[int] = RESNET_NUM_BLOCK, num_middle: int = 16):
+        self.batch, self.device, self.P = batch, device, boxes_per_frame
+        self.flow = FlowStage(flow_sd, batch=batch, device=device)
+        self.prop_g = ProposalStage(prop_general, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True)
+        self.prop_s = ProposalStage(prop_specific, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True)
+        self.refine = RefinementNet(refine_w, num_middle, device)
+        self.masks: Optional[torch.Tensor] = None
+        self.conf: Optional[torch.Tensor] = None
+
+    def step(self, frames_a: torch.Tensor, frames_b: torch.Tensor, boxes_y0x0y1x1: torch.Tensor):
+        """frames_*: uint8 RGB [B,H,W,3] (frame t and t+1); boxes: float [B,P,4] to refine on frame t.
+        Returns dict of device tensors (views of stage buffers, valid until the next step)."""
+        B, H, W, _ = frames_a.shape
+        if self.masks is None or self.masks.shape != (B, self.P, H, W):
+            self.masks = torch.zeros((B, self.P, H, W), dtype=torch.uint8, device=self.device)
+            self.conf = torch.zeros((B, self.P), dtype=torch.float32, device=self.device)
+        flo = self.flow.run(frames_a, frames_b)
+        pg = self.prop_g.run(frames_a)
+        ps = self.prop_s.run(frames_a)
+        for i in range(B):
+            p = self.refine.refine(frames_a[i], boxes_y0x0y1x1[i], max_boxes=self.P)
+            self.masks[i].copy_(p.mask)
+            self.conf[i].copy_(p.conf)
+        return {"flow": flo, "masks": self.masks, "conf": self.conf,
+                "general_boxes": pg.final_boxes, "general_probs": pg.final_probs, "general_count": pg.final_count,
+                "specific_boxes": ps.final_boxes, "specific_probs": ps.final_probs, "specific_count": ps.final_count}
+
+    def conv_steps(self):
+        """(stage, name, launch fn, algorithmic FLOPs) of every conv_igemm launch of one step (bench roofline)."""
+        out = []
+        for tag, steps, flops in (("flow", self.flow.steps, self.flow.plan.flops),
+                                  ("prop_g", self.prop_g.steps, self.prop_g.plan.flops),
+                                  ("prop_s", self.prop_s.steps, self.prop_s.plan.flops)):
+            out += [(tag, n, f, flops[n]) for n, f in steps if n.startswith("conv:")]
+        rp = self.refine.plan(self.P, *self.masks.shape[2:])
+        out += [("refine", n, f, rp.flops[n] * self.batch) for n, f in rp.steps if n.startswith("conv:")]
+        return out

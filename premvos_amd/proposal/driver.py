@@ -64,9 +64,10 @@ class ProposalStage:
 
     def __init__(self, weights: Dict[str, object], batch: int = 1, device: str = "cuda",
                  num_blocks: Sequence[int] = RESNET_NUM_BLOCK, net: Optional[ProposalNet] = None,
-                 use_graph: bool = True):
+                 use_graph: bool = True, rgb_input: bool = False):
         self.net = net if net is not None else ProposalNet(weights, num_blocks, device, use_graph=False)
         self.batch, self.device, self.use_graph = batch, device, use_graph
+        self.rgb_input = rgb_input
         self._shape = None
 
     def _prepare(self, h: int, w: int):
@@ -80,7 +81,8 @@ class ProposalStage:
 
         def pre():
             _lib.check(lib.premvos_proposal_preprocess_u8(self.frames.data_ptr(), b, h, w, p.img.ptr, self.nh, self.nw,
-                                                          _lib.current_stream()), "proposal_preprocess")
+                                                          int(self.rgb_input), _lib.current_stream()),
+                       "proposal_preprocess")
         self.steps = [("proposal_preprocess", pre)] + list(p.steps)
         self.graph = p.capture(self.steps) if self.use_graph else None
         self._shape = (h, w)

@@ -236,7 +236,7 @@ class ProposalNet:
         b, h, w, _ = img_bgr.shape
         p = self.plan(b, h, w)
         _lib.check(_lib.load().premvos_proposal_preprocess_u8(img_bgr.contiguous().data_ptr(), b, h, w, p.img.ptr, h,
-                                                              w, _lib.current_stream()), "proposal_preprocess")
+                                                              w, 0, _lib.current_stream()), "proposal_preprocess")
         if p.graph is not None:
             p.graph.replay()
         else:

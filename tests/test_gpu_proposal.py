@@ -137,9 +137,13 @@ def test_proposal_preprocess_bit_exact():
     ref = P.image_preprocess(torch.from_numpy(R.resize_linear_u8(img, nw, nh)))[0].permute(1, 2, 0)
     out = ops.NHWC.alloc(1, nh, nw, 3)
     _lib.check(_lib.load().premvos_proposal_preprocess_u8(torch.from_numpy(img).cuda().data_ptr(), 1, 60, 107,
-                                                          out.ptr, nh, nw, _lib.current_stream()))
+                                                          out.ptr, nh, nw, 0, _lib.current_stream()))
     got = out.buf[0, :, :, :3].cpu()
     assert (got - ref).abs().max().item() < 1e-6
+    rgb = np.ascontiguousarray(img[:, :, ::-1])
+    _lib.check(_lib.load().premvos_proposal_preprocess_u8(torch.from_numpy(rgb).cuda().data_ptr(), 1, 60, 107,
+                                                          out.ptr, nh, nw, 1, _lib.current_stream()))
+    assert (out.buf[0, :, :, :3].cpu() - ref).abs().max().item() < 1e-6
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
