@@ -21,7 +21,7 @@ class FramePipeline:
     def __init__(self, flow_sd: Dict[str, torch.Tensor], prop_general: Dict[str, object],
                  prop_specific: Dict[str, object], refine_w: Dict[str, object], batch: int = 1,
                  device: str = "cuda", boxes_per_frame: int = RESULTS_PER_IM,
-                 num_blocks: Sequence[int] = RESNET_NUM_BLOCK, num_middle: int = 16):
+                 num_blocks: Sequence[int] = RESNET_NUM_BLOCK, num_middle: int = 16, concurrent: bool = True):
         self.batch, self.device, self.P = batch, device, boxes_per_frame
         self.flow = FlowStage(flow_sd, batch=batch, device=device)
         self.prop_g = ProposalStage(prop_general, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True)
@@ -29,6 +29,10 @@ class FramePipeline:
         self.refine = RefinementNet(refine_w, num_middle, device)
         self.masks: Optional[torch.Tensor] = None
         self.conf: Optional[torch.Tensor] = None
+        # the four stages of a frame are independent: each replays its HIP graph on its own stream so that the
+        # partial last wave of one kernel is filled by another stage's workgroups
+        self.concurrent = concurrent
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(4)] if concurrent else None
 
     def step(self, frames_a: torch.Tensor, frames_b: torch.Tensor, boxes_y0x0y1x1: torch.Tensor):
         """frames_*: uint8 RGB [B,H,W,3] (frame t and t+1); boxes: float [B,P,4] to refine on frame t.
@@ -37,13 +41,29 @@ class FramePipeline:
         if self.masks is None or self.masks.shape != (B, self.P, H, W):
             self.masks = torch.zeros((B, self.P, H, W), dtype=torch.uint8, device=self.device)
             self.conf = torch.zeros((B, self.P), dtype=torch.float32, device=self.device)
-        flo = self.flow.run(frames_a, frames_b)
-        pg = self.prop_g.run(frames_a)
-        ps = self.prop_s.run(frames_a)
-        for i in range(B):
-            p = self.refine.refine(frames_a[i], boxes_y0x0y1x1[i], max_boxes=self.P)
-            self.masks[i].copy_(p.mask)
-            self.conf[i].copy_(p.conf)
+        def refine_all():
+            for i in range(B):
+                p = self.refine.refine(frames_a[i], boxes_y0x0y1x1[i], max_boxes=self.P)
+                self.masks[i].copy_(p.mask)
+                self.conf[i].copy_(p.conf)
+
+        if not self.concurrent:
+            flo = self.flow.run(frames_a, frames_b)
+            pg = self.prop_g.run(frames_a)
+            ps = self.prop_s.run(frames_a)
+            refine_all()
+        else:
+            cur = torch.cuda.current_stream()
+            res = {}
+            jobs = (("r", refine_all), ("g", lambda: self.prop_g.run(frames_a)),
+                    ("s", lambda: self.prop_s.run(frames_a)), ("f", lambda: self.flow.run(frames_a, frames_b)))
+            for st, (k, fn) in zip(self.streams, jobs):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    res[k] = fn()
+            for st in self.streams:
+                cur.wait_stream(st)
+            flo, pg, ps = res["f"], res["g"], res["s"]
         return {"flow": flo, "masks": self.masks, "conf": self.conf,
                 "general_boxes": pg.final_boxes, "general_probs": pg.final_probs, "general_count": pg.final_count,
                 "specific_boxes": ps.final_boxes, "specific_probs": ps.final_probs, "specific_count": ps.final_count}

@@ -1,6 +1,6 @@
 """Dev tool: per-step timing of the full-depth proposal_net at DAVIS shape."""
 import sys, time, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import proposal_oracle as P
 from premvos_amd.proposal import ProposalStage
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

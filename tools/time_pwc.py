@@ -1,6 +1,6 @@
 """Quick per-step timing of the PWC plan (dev tool; bench.py is the contract)."""
 import sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pwc_oracle as O
 from premvos_amd.flow import pwc_dc_net
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -1,6 +1,6 @@
 """Dev tool: per-step timing of the full-depth refinement_net, P boxes on a 480x854 frame."""
 import sys, time, torch, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import refinement_oracle as R
 from premvos_amd.refinement import RefinementNet
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 20
