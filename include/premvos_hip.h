@@ -78,9 +78,16 @@ typedef struct premvos_conv_desc {
   int32_t out_mode;     /* PREMVOS_OUT_*   */
   int32_t cout_ps;      /* PIXSHUF2: channels per phase (cout == 4*cout_ps); out dims are 2ho x 2wo */
   int32_t tile_hint;    /* 0 = auto; else (BM<<16)|BN to force a tile config (bench/tests) */
+  int32_t split_k;      /* 0 = auto, <0 = never, >0 = force this many k-slices */
+  float* workspace;     /* split-K partial slabs (may be NULL: then never split) */
+  int64_t workspace_bytes;
 } premvos_conv_desc;
 
 int premvos_conv2d_f32(const premvos_conv_desc* d, void* stream);
+/* bytes of `workspace` the descriptor needs for its (auto or forced) split-K plan; 0 = runs unsplit.  Layers with
+ * too few output tiles to fill the chip (coarse PWC levels, batch-1 feature maps) are cut along K into slabs that
+ * a second kernel sums in a fixed order before the fused epilogue (deterministic, unlike atomics). */
+int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * PWC-Net cost volume, the only first-party native kernel of the reference:

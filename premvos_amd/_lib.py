@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
         ("dh", C.c_int32), ("dw", C.c_int32), ("pt", C.c_int32), ("pl", C.c_int32),
         ("cin_pad", C.c_int32), ("k_pad", C.c_int32), ("cout_pad", C.c_int32),
         ("act", C.c_int32), ("slope", C.c_float), ("out_mode", C.c_int32), ("cout_ps", C.c_int32),
-        ("tile_hint", C.c_int32),
+        ("tile_hint", C.c_int32), ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -95,6 +95,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.premvos_conv2d_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
+    lib.premvos_conv2d_workspace_bytes.restype = C.c_int64
     lib.premvos_refine_output_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
     lib.premvos_refine_output_workspace_bytes.restype = C.c_int64
     _LIB = lib

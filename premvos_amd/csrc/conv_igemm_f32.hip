@@ -32,8 +32,11 @@ namespace {
 constexpr int BK = 16;           // k depth per LDS stage
 constexpr int RS = BK + 4;       // LDS row stride (floats): 80 B, keeps b128 reads conflict free
 
-template <int BM, int BN, int WM, int WN, bool PIXSHUF>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p) {
+// SPLITK: blockIdx.z owns k-steps [z*kt_per, min(KT,(z+1)*kt_per)) and stores its raw partial tile to
+// p.workspace[z][m][ncols]; splitk_reduce_kernel sums the slabs in z order (deterministic) and applies the
+// epilogue.  Used when a layer has too few output tiles to fill 256 CUs (coarse PWC levels, batch-1 RoI/feature maps).
+template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
@@ -66,10 +69,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     iy0[i] = ok ? oy * p.sh - p.pt : -(1 << 28);  // invalid rows fail the bounds test below
     ix0[i] = ox * p.sw - p.pl;
   }
+  const int KT_all = p.k_pad / BK;
+  const int kt_begin = SPLITK ? blockIdx.z * kt_per : 0;
+  const int kt_end = SPLITK ? (kt_begin + kt_per < KT_all ? kt_begin + kt_per : KT_all) : KT_all;
   int kh, kw, c;
   {
-    const int tap = j4 / p.cin_pad;
-    c = j4 - tap * p.cin_pad;
+    const int k0 = kt_begin * BK + j4;
+    const int tap = k0 / p.cin_pad;
+    c = k0 - tap * p.cin_pad;
     kh = tap / p.kw;
     kw = tap - kh * p.kw;
   }
@@ -125,15 +132,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int KT = p.k_pad / BK;
-  gload(0);
+  const int KT = kt_end - kt_begin;
+  gload(kt_begin);
   lstore(0);
   __syncthreads();
 
   const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) gload(kt + 1);
+    if (kt + 1 < KT) gload(kt_begin + kt + 1);
     const float* a = &lds[buf][wm0 * RS + frag_off];
     const float* b = &lds[buf][(BM + wn0) * RS + frag_off];
 #pragma unroll
@@ -157,6 +164,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     __syncthreads();
   }
 
+  if constexpr (SPLITK) {   // raw partial slab, ncols = gridDim.y * BN (padded: no column predicate needed)
+    const int ncols = gridDim.y * BN;
+    float* ws = p.workspace + (long)blockIdx.z * M * ncols;
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni) {
+      const int col = n0 + wn0 + ni * 32 + (lane & 31);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) ws[(long)m * ncols + col] = acc[mi][ni][r];
+        }
+    }
+    return;
+  }
   // ---- epilogue: bias + residual + activation, 128-byte channel runs per pixel -------------
 #pragma unroll
   for (int ni = 0; ni < NTL; ++ni) {
@@ -189,16 +212,103 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
   }
 }
 
+// Sum the split-K slabs in fixed order and apply the fused epilogue (bias, residual, activation, layout).
+template <bool PIXSHUF>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const premvos_conv_desc p, const int splits, const int ncols) {
+  const int M = p.n * p.ho * p.wo;
+  const long total = (long)M * p.cout;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int col = idx % p.cout;
+    const int m = idx / p.cout;
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += p.workspace[((long)z * M + m) * ncols + col];
+    if (p.bias != nullptr) v += p.bias[col];
+    if (p.res != nullptr) v += p.res[(long)m * p.res_ps + col];
+    if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (p.act == PREMVOS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+    if constexpr (PIXSHUF) {
+      const int hw = p.ho * p.wo;
+      const int n = m / hw, rem = m - n * hw;
+      const int oy = rem / p.wo, ox = rem - oy * p.wo;
+      const int phase = col / p.cout_ps, co = col - phase * p.cout_ps;
+      const long opix = ((long)n * 2 * p.ho + 2 * oy + (phase >> 1)) * (2 * p.wo) + 2 * ox + (phase & 1);
+      p.out[opix * p.out_ps + co] = v;
+    } else {
+      p.out[(long)m * p.out_ps + col] = v;
+    }
+  }
+}
+
+// how many k-slices a layer is cut into (1 = no split): aim for >= ~3 workgroups per CU
+inline int pick_splits(const premvos_conv_desc& d, int bm, int bn) {
+  if (d.split_k > 0) return d.split_k;
+  if (d.split_k < 0) return 1;
+  const long tiles = (long)premvos::cdiv(d.n * d.ho * d.wo, bm) * premvos::cdiv(d.cout, bn);
+  const int KT = d.k_pad / BK;
+  if (tiles >= 384 || KT < 16) return 1;
+  long s = (768 + tiles - 1) / tiles;
+  if (s > KT / 8) s = KT / 8;
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : (int)s;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   const int M = d.n * d.ho * d.wo;
   dim3 grid(premvos::cdiv(M, BM), premvos::cdiv(d.cout, BN));
   dim3 block(64 * WM * WN);
+  int splits = pick_splits(d, BM, BN);
+  const int KT = d.k_pad / BK;
+  if (splits > 1) {
+    const int kt_per = premvos::cdiv(KT, splits);
+    splits = premvos::cdiv(KT, kt_per);
+    const int ncols = grid.y * BN;
+    const long need = (long)splits * M * ncols * sizeof(float);
+    if (splits > 1 && d.workspace != nullptr && (long)d.workspace_bytes >= need) {
+      grid.z = splits;
+      hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, d, kt_per);
+      int rc = premvos::check_launch("conv_igemm_f32(split-k)");
+      if (rc) return rc;
+      long total = (long)M * d.cout;
+      int g = (int)((total + 255) / 256);
+      if (g > 4096) g = 4096;
+      if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(g), dim3(256), 0, s, d, splits, ncols);
+      else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(g), dim3(256), 0, s, d, splits, ncols);
+      return premvos::check_launch("splitk_reduce");
+    }
+    if (d.split_k > 0) return premvos::fail(PREMVOS_EINVAL, "conv2d: split_k=%d needs %ld workspace bytes", d.split_k, need);
+  }
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, d);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, d, 0);
   else
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, d);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, d, 0);
   return premvos::check_launch("conv_igemm_f32");
+}
+
+template <int BM, int BN, int WM, int WN>
+long ws_cfg(const premvos_conv_desc& d) {
+  int splits = pick_splits(d, BM, BN);
+  if (splits <= 1) return 0;
+  const int KT = d.k_pad / BK;
+  const int kt_per = premvos::cdiv(KT, splits);
+  splits = premvos::cdiv(KT, kt_per);
+  if (splits <= 1) return 0;
+  return (long)splits * d.n * d.ho * d.wo * premvos::cdiv(d.cout, BN) * BN * (long)sizeof(float);
+}
+
+inline void pick_tile(const premvos_conv_desc& d, int* bm, int* bn) {
+  const int M = d.n * d.ho * d.wo;
+  if (d.tile_hint) {
+    *bm = d.tile_hint >> 16;
+    *bn = d.tile_hint & 0xffff;
+    return;
+  }
+  *bn = d.cout <= 32 ? 32 : d.cout <= 64 ? 64 : d.cout <= 96 ? 96 : 128;
+  const long blocks128 = (long)premvos::cdiv(M, 128) * premvos::cdiv(d.cout, *bn);
+  *bm = blocks128 >= 512 ? 128 : 64;
+  if (*bn == 96 && *bm == 64) *bn = 128;  // (64,96) is not instantiated
 }
 
 }  // namespace
@@ -226,17 +336,8 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   PV_REQUIRE((long)d.n * d.ho * d.wo < (1L << 31), "conv2d: too many output pixels");
 
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int M = d.n * d.ho * d.wo;
   int bm, bn;
-  if (d.tile_hint) {
-    bm = d.tile_hint >> 16;
-    bn = d.tile_hint & 0xffff;
-  } else {
-    bn = d.cout <= 32 ? 32 : d.cout <= 64 ? 64 : d.cout <= 96 ? 96 : 128;
-    const long blocks128 = (long)premvos::cdiv(M, 128) * premvos::cdiv(d.cout, bn);
-    bm = blocks128 >= 512 ? 128 : 64;
-    if (bn == 96 && bm == 64) bn = 128;  // (64,96) is not instantiated
-  }
+  pick_tile(d, &bm, &bn);
   switch ((bm << 16) | bn) {
     case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2>(d, s);
     case (128 << 16) | 96: return launch_cfg<128, 96, 4, 1>(d, s);
@@ -249,5 +350,21 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   }
 }
 
+extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
+  if (dp == nullptr || dp->k_pad <= 0 || dp->n <= 0 || dp->ho <= 0 || dp->wo <= 0 || dp->cout <= 0) return 0;
+  int bm, bn;
+  pick_tile(*dp, &bm, &bn);
+  switch ((bm << 16) | bn) {
+    case (128 << 16) | 128: return ws_cfg<128, 128, 2, 2>(*dp);
+    case (128 << 16) | 96: return ws_cfg<128, 96, 4, 1>(*dp);
+    case (128 << 16) | 64: return ws_cfg<128, 64, 2, 2>(*dp);
+    case (128 << 16) | 32: return ws_cfg<128, 32, 4, 1>(*dp);
+    case (64 << 16) | 128: return ws_cfg<64, 128, 2, 2>(*dp);
+    case (64 << 16) | 64: return ws_cfg<64, 64, 2, 2>(*dp);
+    case (64 << 16) | 32: return ws_cfg<64, 32, 2, 1>(*dp);
+    default: return 0;
+  }
+}
+
 extern "C" const char* premvos_last_error(void) { return premvos::g_err; }
-extern "C" int premvos_abi_version(void) { return 1; }
+extern "C" int premvos_abi_version(void) { return 2; }

@@ -58,10 +58,12 @@ class _Plan:
             return v
 
         self.flops: Dict[str, float] = {}   # algorithmic FLOPs (2*MAC, true cin/cout) per conv launch
+        self.descs: List = []
 
         def conv(x, name, out, **kw):
             pk = P[name]
             d = ops.conv_desc(x, pk, out, **kw)
+            self.descs.append(d)
             steps.append(("conv:" + name, lambda d=d: ops.run_desc(d)))
             if pk.cout_ps:   # transposed conv k4 s2: every input pixel feeds 16 taps
                 self.flops["conv:" + name] = 2.0 * x.n * x.h * x.w * 16 * pk.cin * pk.cout_ps
@@ -146,6 +148,7 @@ class _Plan:
         steps.append(("nhwc_to_nchw", lambda s=flow2, d=self.flow_out: ops.nhwc_to_nchw(s, d)))
         self.steps = steps
         self.buffers = keep
+        self.ws = ops.assign_workspace(self.descs, dev)      # split-K scratch shared by the whole launch list
         self.feats, self.xbufs = feats, xbufs
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 

@@ -112,7 +112,7 @@ def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
 
 
 def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1), pad=(0, 0),
-              act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None, tile_hint: int = 0) -> ConvDesc:
+              act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None, tile_hint: int = 0, split_k: int = 0) -> ConvDesc:
     """Build the descriptor (validated again on the C side).  ``pad`` = (top, left); the output
     size comes from ``out`` so asymmetric bottom/right padding is implicit."""
     assert x.c == pk.cin, (x.c, pk.cin)
@@ -139,11 +139,29 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     d.cin_pad, d.k_pad, d.cout_pad = pk.cin_pad, pk.k_pad, pk.cout_pad
     d.act, d.slope = act, slope
     d.tile_hint = tile_hint
+    d.split_k = split_k
+    d.workspace, d.workspace_bytes = None, 0
     return d
+
+
+def workspace_bytes(d: ConvDesc) -> int:
+    return int(_lib.load().premvos_conv2d_workspace_bytes(C.byref(d)))
+
+
+def assign_workspace(descs, device="cuda") -> Optional[torch.Tensor]:
+    """One split-K scratch buffer shared by all convs of a (stream-ordered) launch list."""
+    need = max([workspace_bytes(d) for d in descs] + [0])
+    if need == 0:
+        return None
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    for d in descs:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    return ws
 
 
 def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):
     d = conv_desc(x, pk, out, **kw)
+    ws = assign_workspace([d], x.buf.device)          # noqa: F841  (kept alive until the launch is enqueued)
     _lib.check(_lib.load().premvos_conv2d_f32(C.byref(d), _lib.current_stream()), "conv2d")
     return out
 

@@ -70,6 +70,7 @@ class _Plan:
         steps: List = []
         keep: List = []
         self.flops: Dict[str, float] = {}
+        self.descs: List = []
 
         def alloc(n, hh, ww, c):
             v = NHWC.alloc(n, hh, ww, c, dev)
@@ -79,6 +80,7 @@ class _Plan:
         def conv(x, name, out, uid=None, **kw):
             pk = P[name]
             d = ops.conv_desc(x, pk, out, **kw)
+            self.descs.append(d)
             key = "conv:" + (uid or name)
             steps.append((key, lambda d=d: ops.run_desc(d)))
             self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
@@ -177,6 +179,7 @@ class _Plan:
                 self.final_count.data_ptr(), _lib.current_stream()), "frcnn_tail")
         steps.append(("frcnn_tail", tail))
         self.steps, self.buffers = steps, keep
+        self.ws_splitk = ops.assign_workspace(self.descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def run(self, steps=None):

@@ -76,6 +76,7 @@ class _Plan:
         PK, DW = net.packed, net.packed_dw
         steps: List = []
         self.flops: Dict[str, float] = {}
+        self.descs: List = []
         self.dw_bytes: Dict[str, float] = {}
         pool: Dict[tuple, List[NHWC]] = {}
         keep: List[NHWC] = []
@@ -94,6 +95,7 @@ class _Plan:
         def conv(x, name, out, **kw):
             pk = PK[name]
             d = ops.conv_desc(x, pk, out, **kw)
+            self.descs.append(d)
             key = f"conv:{name}"
             steps.append((key, lambda d=d: ops.run_desc(d)))
             self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
@@ -219,6 +221,7 @@ class _Plan:
                 self.conf.data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
         steps.append(("refine_output", out_layer))
         self.steps, self.buffers = steps, keep
+        self.ws_splitk = ops.assign_workspace(self.descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def run(self, steps=None):

@@ -169,3 +169,44 @@ def test_layout_roundtrip():
     assert torch.equal(back.cpu(), x)
     assert torch.equal(v.buf[..., :37].cpu(), x.permute(0, 2, 3, 1))
     assert v.buf[..., 37:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("case", [(1, 661, 16, 28, 128, 3, 0), (2, 1024, 6, 9, 256, 1, 0), (1, 117, 8, 14, 2, 3, 5),
+                                  (1, 597, 32, 56, 96, 3, 3)])
+def test_conv2d_split_k_deterministic_and_exact(case):
+    """Small-M / long-K layers are cut along K; result equals the unsplit kernel to fp32 round-off and is bitwise
+    reproducible run to run (fixed-order slab reduction, no atomics)."""
+    ops = _ops()
+    n, cin, h, w, cout, k, force = case
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    res = torch.randn((n, cout, h, w), generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=k // 2) + res.double(), 0.1)
+    xin, pk, rr = _to_nhwc(x, ops), ops.pack_conv(wt, b), _to_nhwc(res, ops)
+    outs = []
+    for sk in (force, force, -1):
+        out = _to_nhwc(torch.zeros(ref.shape), ops, coff=3, ps=cout + 5)
+        d = ops.conv_desc(xin, pk, out, pad=(k // 2, k // 2), act=ops.ACT_LEAKY, res=rr, split_k=sk)
+        if sk >= 0:
+            assert ops.workspace_bytes(d) > 0          # auto mode decides to split these shapes
+        ops.conv2d(xin, pk, out, pad=(k // 2, k // 2), act=ops.ACT_LEAKY, res=rr, split_k=sk)
+        torch.cuda.synchronize()
+        outs.append(out.torch().cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].double() - ref).abs().max().item() < 2e-4
+    assert (outs[0] - outs[2]).abs().max().item() < 1e-4
+
+
+def test_deconv_split_k_pixel_shuffle():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((1, 661, 8, 14), generator=g)
+    wt = torch.randn((661, 2, 4, 4), generator=g) * 0.05
+    b = torch.randn((2,), generator=g)
+    ref = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
+    out = _to_nhwc(torch.zeros(ref.shape), ops, coff=1, ps=8)
+    ops.conv2d(_to_nhwc(x, ops), ops.pack_deconv4x4s2(wt, b), out, pad=(1, 1), split_k=4)
+    torch.cuda.synchronize()
+    assert (out.torch().cpu().double() - ref).abs().max().item() < 2e-4
