@@ -140,8 +140,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("PREMVOS_BENCH_FORCE_DIST") == "1"     # exercise the gather path on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -163,14 +165,15 @@ def main():
     boxes = synth_boxes(B, rank).to(dev)
 
     gbuf = None
-    if world > 1 and rank == 0:
+    use_dist = world > 1 or force_dist
+    if use_dist and rank == 0:
         gbuf = {"flow": [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(world)],
                 "masks": [torch.empty((B, P_BOXES, H, W), dtype=torch.uint8, device=dev) for _ in range(world)],
                 "small": [torch.empty((B, 2 * 20 * 5 + P_BOXES + 2), dtype=torch.float32, device=dev) for _ in range(world)]}
 
     def step():
         r = pipe.step(fa, fb, boxes)
-        if world > 1:       # the single exchange of the path: results -> merge rank
+        if use_dist:        # the single exchange of the path: results -> merge rank
             small = torch.cat([r["general_boxes"].reshape(B, -1), r["general_probs"], r["specific_boxes"].reshape(B, -1),
                                r["specific_probs"], r["conf"], r["general_count"].view(B, 1).float(),
                                r["specific_count"].view(B, 1).float()], 1).contiguous()
@@ -181,18 +184,18 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -217,7 +220,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
