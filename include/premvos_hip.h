@@ -36,6 +36,11 @@ extern "C" {
 #define PREMVOS_ACT_RELU 1
 #define PREMVOS_ACT_LEAKY 2 /* x > 0 ? x : slope * x   (nn.LeakyReLU(0.1), PWCNet.py:28) */
 
+/* arithmetic of the dense-conv MFMA pipe (activations and outputs are fp32 in HBM in every mode) */
+#define PREMVOS_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products (the parity / default bench mode)        */
+#define PREMVOS_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16 on bf16(a), bf16(b), fp32 accumulate                        */
+#define PREMVOS_PREC_BF16X3 3 /* split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate (~2^-17 relative per product)    */
+
 /* output scatter mode of the conv epilogue */
 #define PREMVOS_OUT_NHWC 0
 #define PREMVOS_OUT_PIXSHUF2 1 /* column j = phase*cout_ps + co -> out[2y+phase/2][2x+phase%2][co] */
@@ -81,6 +86,9 @@ typedef struct premvos_conv_desc {
   int32_t split_k;      /* 0 = auto, <0 = never, >0 = force this many k-slices */
   float* workspace;     /* split-K partial slabs (may be NULL: then never split) */
   int64_t workspace_bytes;
+  int32_t precision;    /* PREMVOS_PREC_*; bf16 modes: wgt = bf16 hi [cout_pad][k_pad], k_pad % 32 == 0 */
+  int32_t reserved0;
+  const void* wgt_lo;   /* BF16X3: bf16 low parts (w - float(hi)), same shape as wgt */
 } premvos_conv_desc;
 
 int premvos_conv2d_f32(const premvos_conv_desc* d, void* stream);

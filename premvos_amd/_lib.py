@@ -17,6 +17,8 @@ _LIB = None
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 OUT_NHWC, OUT_PIXSHUF2 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
+PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
 
 class ConvDesc(C.Structure):
@@ -33,6 +35,7 @@ class ConvDesc(C.Structure):
         ("cin_pad", C.c_int32), ("k_pad", C.c_int32), ("cout_pad", C.c_int32),
         ("act", C.c_int32), ("slope", C.c_float), ("out_mode", C.c_int32), ("cout_ps", C.c_int32),
         ("tile_hint", C.c_int32), ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("precision", C.c_int32), ("reserved0", C.c_int32), ("wgt_lo", C.c_void_p),
     ]
 
 

@@ -23,6 +23,8 @@
 
 namespace premvos {
 thread_local char g_err[512] = "";
+int conv2d_bf16(const premvos_conv_desc& d, hipStream_t s);               // conv_igemm_bf16.hip
+long conv2d_bf16_workspace_bytes(const premvos_conv_desc& d);
 }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -239,6 +241,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const premvos_conv_d
   }
 }
 
+}  // namespace
+
+namespace premvos {
+int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s) {
+  const long total = (long)d.n * d.ho * d.wo * d.cout;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
+    hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(g), dim3(256), 0, s, d, splits, ncols);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(g), dim3(256), 0, s, d, splits, ncols);
+  return check_launch("splitk_reduce");
+}
+}  // namespace premvos
+
+namespace {
+
 // how many k-slices a layer is cut into (1 = no split): aim for >= ~3 workgroups per CU
 inline int pick_splits(const premvos_conv_desc& d, int bm, int bn) {
   if (d.split_k > 0) return d.split_k;
@@ -269,14 +288,7 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
       hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, d, kt_per);
       int rc = premvos::check_launch("conv_igemm_f32(split-k)");
       if (rc) return rc;
-      long total = (long)M * d.cout;
-      int g = (int)((total + 255) / 256);
-      if (g > 4096) g = 4096;
-      if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
-        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(g), dim3(256), 0, s, d, splits, ncols);
-      else
-        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(g), dim3(256), 0, s, d, splits, ncols);
-      return premvos::check_launch("splitk_reduce");
+      return premvos::launch_splitk_reduce(d, splits, ncols, s);
     }
     if (d.split_k > 0) return premvos::fail(PREMVOS_EINVAL, "conv2d: split_k=%d needs %ld workspace bytes", d.split_k, need);
   }
@@ -322,6 +334,8 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   PV_REQUIRE(d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.dh > 0 && d.dw > 0, "conv2d: bad kernel geometry");
   PV_REQUIRE(d.cin_pad == (d.cin + 3) / 4 * 4, "conv2d: cin_pad must be roundup(cin,4)");
   PV_REQUIRE(d.k_pad % BK == 0 && d.k_pad >= d.kh * d.kw * d.cin_pad, "conv2d: bad k_pad");
+  PV_REQUIRE(d.precision == PREMVOS_PREC_F32 || d.precision == PREMVOS_PREC_BF16 || d.precision == PREMVOS_PREC_BF16X3,
+             "conv2d: bad precision");
   PV_REQUIRE(d.cout_pad % 32 == 0 && d.cout_pad >= d.cout, "conv2d: bad cout_pad");
   PV_REQUIRE(d.in_ps % 4 == 0 && d.in_ps >= d.cin_pad, "conv2d: input pixel stride must be a multiple of 4 and >= cin_pad");
   PV_REQUIRE(premvos::aligned16(d.in) && premvos::aligned16(d.wgt), "conv2d: in/wgt must be 16-byte aligned");
@@ -336,6 +350,7 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   PV_REQUIRE((long)d.n * d.ho * d.wo < (1L << 31), "conv2d: too many output pixels");
 
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d.precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16(d, s);
   int bm, bn;
   pick_tile(d, &bm, &bn);
   switch ((bm << 16) | bn) {
@@ -352,6 +367,7 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
 
 extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   if (dp == nullptr || dp->k_pad <= 0 || dp->n <= 0 || dp->ho <= 0 || dp->wo <= 0 || dp->cout <= 0) return 0;
+  if (dp->precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16_workspace_bytes(*dp);
   int bm, bn;
   pick_tile(*dp, &bm, &bn);
   switch ((bm << 16) | bn) {
@@ -367,4 +383,4 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
 }
 
 extern "C" const char* premvos_last_error(void) { return premvos::g_err; }
-extern "C" int premvos_abi_version(void) { return 2; }
+extern "C" int premvos_abi_version(void) { return 3; }

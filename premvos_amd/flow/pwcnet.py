@@ -179,8 +179,9 @@ class _Plan:
 class PWCDCNet:
     """Drop-in for ``models.PWCNet.PWCDCNet`` (inference).  ``__call__`` == ``forward`` in eval mode."""
 
-    def __init__(self, md: int = 4, device: str = "cuda", use_graph: bool = True):
+    def __init__(self, md: int = 4, device: str = "cuda", use_graph: bool = True, precision: Optional[str] = None):
         assert md == MD, "PWC-Net is instantiated with md=4 (PWCNet.py:43)"
+        self.precision = precision or ops.default_precision()
         self.device = device
         self.use_graph = use_graph
         self.training = False
@@ -203,9 +204,9 @@ class PWCDCNet:
             w, bia = sd[full + ".weight"], sd.get(full + ".bias")
             key = full[:-2] if full.endswith(".0") else full
             if key.startswith(("deconv", "upfeat")):
-                packed[key] = ops.pack_deconv4x4s2(w, bia, self.device)
+                packed[key] = ops.pack_deconv4x4s2(w, bia, self.device, self.precision)
             else:
-                packed[key] = ops.pack_conv(w, bia, self.device)
+                packed[key] = ops.pack_conv(w, bia, self.device, precision=self.precision)
         if strict:
             need = set()
             for lv in PYR.values():
@@ -250,9 +251,10 @@ class PWCDCNet:
     __call__ = forward
 
 
-def pwc_dc_net(path: Optional[str] = None, device: str = "cuda", use_graph: bool = True) -> PWCDCNet:
+def pwc_dc_net(path: Optional[str] = None, device: str = "cuda", use_graph: bool = True,
+               precision: Optional[str] = None) -> PWCDCNet:
     """models/PWCNet.py:496-505."""
-    model = PWCDCNet(device=device, use_graph=use_graph)
+    model = PWCDCNet(device=device, use_graph=use_graph, precision=precision)
     if path is not None:
         data = torch.load(path, map_location="cpu")
         model.load_state_dict(data["state_dict"] if "state_dict" in data else data)

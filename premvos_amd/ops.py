@@ -65,19 +65,28 @@ class PackedConv:
     k_pad: int
     cout_pad: int
     cout_ps: int = 0          # >0: transposed-conv phases (PIXSHUF2)
+    precision: int = 0        # _lib.PREC_*; bf16 modes: wgt / wgt_lo are bfloat16 [cout_pad][k_pad], k_pad % 32 == 0
+    wgt_lo: Optional[torch.Tensor] = None
+
+
+def default_precision() -> str:
+    import os
+    return os.environ.get("PREMVOS_PRECISION", "fp32")
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
-              scale: Optional[torch.Tensor] = None) -> PackedConv:
+              scale: Optional[torch.Tensor] = None, precision: str = "fp32") -> PackedConv:
     """OIHW fp32 -> [cout_pad][k_pad] with k = (kh*KW+kw)*cin_pad + c.  ``scale`` (per cout)
-    folds a frozen BatchNorm's gamma/sqrt(var+eps) into the weights."""
+    folds a frozen BatchNorm's gamma/sqrt(var+eps) into the weights.  precision 'bf16' / 'bf16x3': the matrix
+    is stored as bfloat16 high parts (+ low parts w - float(hi)) and k is padded to 32."""
+    prec = _lib.PRECISIONS[precision]
     w = weight.detach().to(torch.float32).cpu()
     cout, cin, kh, kw = w.shape
     if scale is not None:
         w = w * scale.detach().to(torch.float32).cpu().view(-1, 1, 1, 1)
     cin_pad, cout_pad = _r(cin, 4), _r(cout, 32)
     k = kh * kw * cin_pad
-    k_pad = _r(k, 16)
+    k_pad = _r(k, 16 if prec == _lib.PREC_F32 else 32)
     p = torch.zeros((cout_pad, kh * kw, cin_pad), dtype=torch.float32)
     p[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
     full = torch.zeros((cout_pad, k_pad), dtype=torch.float32)
@@ -87,10 +96,16 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
         b = torch.zeros(cout_pad, dtype=torch.float32)
         b[:cout] = bias.detach().to(torch.float32).cpu()
         b = b.to(device)
-    return PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
+    if prec == _lib.PREC_F32:
+        return PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
+    hi = full.to(torch.bfloat16)
+    lo = (full - hi.float()).to(torch.bfloat16) if prec == _lib.PREC_BF16X3 else None
+    return PackedConv(hi.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec,
+                      lo.to(device).contiguous() if lo is not None else None)
 
 
-def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda") -> PackedConv:
+def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
+                     precision: str = "fp32") -> PackedConv:
     """ConvTranspose2d(k=4,s=2,p=1) weights [cin,cout,4,4] -> the equivalent 3x3 conv with
     4*cout phase outputs (phase = 2*py+px writes out[2y+py][2x+px]).  For output row 2y+py the
     contributing input rows are y+dy with  py=0: (dy=0,ky=1),(dy=-1,ky=3);  py=1: (dy=0,ky=2),(dy=+1,ky=0)."""
@@ -106,7 +121,7 @@ def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
                 for dx, kx in taps[px]:
                     w3[ph * cout:(ph + 1) * cout, :, dy + 1, dx + 1] = w[:, :, ky, kx].t()
     b4 = None if bias is None else bias.detach().to(torch.float32).cpu().repeat(4)
-    pk = pack_conv(w3, b4, device)
+    pk = pack_conv(w3, b4, device, precision=precision)
     pk.cout_ps = cout
     return pk
 
@@ -141,6 +156,8 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     d.tile_hint = tile_hint
     d.split_k = split_k
     d.workspace, d.workspace_bytes = None, 0
+    d.precision = pk.precision
+    d.wgt_lo = pk.wgt_lo.data_ptr() if pk.wgt_lo is not None else None
     return d
 
 

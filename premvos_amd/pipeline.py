@@ -21,12 +21,16 @@ class FramePipeline:
     def __init__(self, flow_sd: Dict[str, torch.Tensor], prop_general: Dict[str, object],
                  prop_specific: Dict[str, object], refine_w: Dict[str, object], batch: int = 1,
                  device: str = "cuda", boxes_per_frame: int = RESULTS_PER_IM,
-                 num_blocks: Sequence[int] = RESNET_NUM_BLOCK, num_middle: int = 16, concurrent: bool = True):
+                 num_blocks: Sequence[int] = RESNET_NUM_BLOCK, num_middle: int = 16, concurrent: bool = True,
+                 precision: Optional[str] = None):
         self.batch, self.device, self.P = batch, device, boxes_per_frame
-        self.flow = FlowStage(flow_sd, batch=batch, device=device)
-        self.prop_g = ProposalStage(prop_general, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True)
-        self.prop_s = ProposalStage(prop_specific, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True)
-        self.refine = RefinementNet(refine_w, num_middle, device)
+        self.precision = precision
+        self.flow = FlowStage(flow_sd, batch=batch, device=device, precision=precision)
+        self.prop_g = ProposalStage(prop_general, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True,
+                                    precision=precision)
+        self.prop_s = ProposalStage(prop_specific, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True,
+                                    precision=precision)
+        self.refine = RefinementNet(refine_w, num_middle, device, precision=precision)
         self.masks: Optional[torch.Tensor] = None
         self.conf: Optional[torch.Tensor] = None
         # the four stages of a frame are independent: each replays its HIP graph on its own stream so that the

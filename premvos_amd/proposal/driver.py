@@ -64,8 +64,9 @@ class ProposalStage:
 
     def __init__(self, weights: Dict[str, object], batch: int = 1, device: str = "cuda",
                  num_blocks: Sequence[int] = RESNET_NUM_BLOCK, net: Optional[ProposalNet] = None,
-                 use_graph: bool = True, rgb_input: bool = False):
-        self.net = net if net is not None else ProposalNet(weights, num_blocks, device, use_graph=False)
+                 use_graph: bool = True, rgb_input: bool = False, precision: Optional[str] = None):
+        self.net = net if net is not None else ProposalNet(weights, num_blocks, device, use_graph=False,
+                                                           precision=precision)
         self.batch, self.device, self.use_graph = batch, device, use_graph
         self.rgb_input = rgb_input
         self._shape = None

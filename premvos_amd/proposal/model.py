@@ -206,8 +206,9 @@ class ProposalNet:
     beta, mean, var), 'rpn/{conv0,class,box}/{W,b}', 'fastrcnn/{class,box}/{W,b}', 'secondclassification/class/{W,b}'."""
 
     def __init__(self, weights: Dict[str, object], num_blocks: Sequence[int] = RESNET_NUM_BLOCK,
-                 device: str = "cuda", use_graph: bool = True):
+                 device: str = "cuda", use_graph: bool = True, precision: Optional[str] = None):
         _lib.require_gpu()
+        self.precision = prec = precision or ops.default_precision()
         self.device, self.use_graph, self.num_blocks = device, use_graph, tuple(num_blocks)
         self.packed: Dict[str, ops.PackedConv] = {}
         self._plans: Dict[tuple, _Plan] = {}
@@ -215,13 +216,13 @@ class ProposalNet:
         w = weights
         for name in [k[:-2] for k in w if k.endswith("/W") and (k[:-2] + "/bn") in w]:
             scale, bias = _fold_bn(w[name + "/bn"])
-            self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale)
-        self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device)
+            self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale, precision=prec)
+        self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device, precision=prec)
         self.packed["rpn/heads"] = ops.pack_conv(torch.cat([w["rpn/class/W"], w["rpn/box/W"]], 0),
-                                                 torch.cat([w["rpn/class/b"], w["rpn/box/b"]], 0), device)
+                                                 torch.cat([w["rpn/class/b"], w["rpn/box/b"]], 0), device, precision=prec)
         hw = torch.cat([w["fastrcnn/class/W"], w["fastrcnn/box/W"], w["secondclassification/class/W"]], 0)
         hb = torch.cat([w["fastrcnn/class/b"], w["fastrcnn/box/b"], w["secondclassification/class/b"]], 0)
-        self.packed["heads"] = ops.pack_conv(hw.view(hw.shape[0], hw.shape[1], 1, 1), hb, device)
+        self.packed["heads"] = ops.pack_conv(hw.view(hw.shape[0], hw.shape[1], 1, 1), hb, device, precision=prec)
 
     def plan(self, b: int, h: int, w: int) -> _Plan:
         key = (b, h, w)

@@ -247,8 +247,10 @@ class RefinementNet:
     '<scope>/weights' OIHW, '<scope>/depthwise_weights' [C,1,3,3], '<scope>/BatchNorm' = dict(gamma,beta,mean,var),
     'logits/features/biases'."""
 
-    def __init__(self, weights: Dict[str, object], num_middle: int = 16, device: str = "cuda", use_graph: bool = True):
+    def __init__(self, weights: Dict[str, object], num_middle: int = 16, device: str = "cuda", use_graph: bool = True,
+                 precision: Optional[str] = None):
         _lib.require_gpu()
+        self.precision = prec = precision or ops.default_precision()
         self.device, self.use_graph, self.num_middle = device, use_graph, num_middle
         self.packed: Dict[str, ops.PackedConv] = {}
         self.packed_dw: Dict[str, PackedDW] = {}
@@ -262,9 +264,9 @@ class RefinementNet:
             elif k.endswith("/weights"):
                 if scope + "/BatchNorm" in weights:
                     scale, bias = _fold(weights[scope + "/BatchNorm"], eps)
-                    self.packed[scope] = ops.pack_conv(v, bias, device, scale=scale)
+                    self.packed[scope] = ops.pack_conv(v, bias, device, scale=scale, precision=prec)
                 else:
-                    self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device)
+                    self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device, precision=prec)
 
     def plan(self, P: int, H: int, W: int, with_posterior: bool = False) -> _Plan:
         key = (P, H, W, with_posterior)

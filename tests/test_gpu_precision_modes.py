@@ -1,0 +1,99 @@
+"""The bf16-MFMA modes of the dense conv (PREMVOS_PREC_BF16 / BF16X3): configs[2]/[4] of BASELINE.json ask for bf16
+compute.  fp32 stays the parity/default mode; these tests state (and bound) what the two faster modes cost in accuracy."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import proposal_oracle as PO  # noqa: E402
+from oracle import pwc_oracle as O  # noqa: E402
+from oracle import refinement_oracle as RO  # noqa: E402
+
+CASES = [(2, 3, 40, 44, 16, 3, 2, 1), (1, 117, 32, 48, 128, 3, 1, 1), (1, 565, 16, 24, 2, 3, 1, 1),
+         (1, 128, 20, 20, 96, 3, 1, 8), (2, 64, 31, 29, 256, 1, 1, 1), (1, 728, 25, 25, 728, 1, 1, 1),
+         (1, 661, 8, 14, 128, 3, 1, 1), (1, 256, 30, 30, 128, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16", 1.5e-2)])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_precision_modes(case, prec, tol):
+    from premvos_amd import ops
+    n, cin, h, w, cout, k, s, dil = case
+    g = torch.Generator().manual_seed(cin * k + cout)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    pad = dil * (k // 2)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), stride=s, dilation=dil, padding=pad), 0.1)
+    xin = ops.NHWC.alloc(n, h, w, cin)
+    xin.buf[..., :cin] = x.permute(0, 2, 3, 1).cuda()
+    out = ops.NHWC.alloc(n, ref.shape[2], ref.shape[3], cout)
+    pk = ops.pack_conv(wt, b, precision=prec)
+    ops.conv2d(xin, pk, out, stride=(s, s), dilation=(dil, dil), pad=(pad, pad), act=ops.ACT_LEAKY)
+    torch.cuda.synchronize()
+    err = (out.torch().cpu().double() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
+
+
+def test_deconv_and_splitk_in_bf16x3():
+    from premvos_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((1, 661, 8, 14), generator=g)
+    wt = torch.randn((661, 2, 4, 4), generator=g) * 0.05
+    b = torch.randn((2,), generator=g)
+    ref = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
+    xin = ops.NHWC.alloc(1, 8, 14, 661)
+    xin.buf[..., :661] = x.permute(0, 2, 3, 1).cuda()
+    for sk in (-1, 4):
+        out = ops.NHWC.alloc(1, 16, 28, 2)
+        ops.conv2d(xin, ops.pack_deconv4x4s2(wt, b, precision="bf16x3"), out, pad=(1, 1), split_k=sk)
+        torch.cuda.synchronize()
+        assert (out.torch().cpu().double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-3), ("bf16", 0.5)])
+def test_pwc_net_precision_modes(prec, tol):
+    from premvos_amd.flow import pwc_dc_net
+    sd = O.synth_state_dict(1)
+    x = O.synth_frame_pair(128, 192, seed=12, shift=(1.5, -0.75))
+    with torch.no_grad():
+        ref = O.pwc_forward(sd, x)
+    net = pwc_dc_net(None, precision=prec)
+    net.load_state_dict(sd)
+    got = net(x.cuda()).cpu()
+    err = (got - ref).abs().max().item()
+    print(f"PWC-Net {prec}: max |flow err| = {err:.3e} (|flow| max {ref.abs().max().item():.2f})")
+    assert err < tol * max(1.0, ref.abs().max().item())
+
+
+def test_proposal_and_refinement_bf16x3_stay_within_fp32_tolerances():
+    """bf16x3 is accurate enough for the same 1e-3 bars as fp32 on the reduced-depth nets."""
+    from premvos_amd.proposal import OfflinePredictor, ProposalNet
+    from premvos_amd.refinement import RefinementNet
+    w = PO.synth_weights(1, (2, 2, 3, 2))
+    img = np.random.default_rng(1).integers(0, 256, (160, 256, 3), dtype=np.uint8)
+    (fb, fp, fl, fi), inter = PO.model_forward(w, img, (2, 2, 3, 2), intermediates=True)
+    net = ProposalNet(w, (2, 2, 3, 2), precision="bf16x3")
+    OfflinePredictor(net)(img)
+    p = net.plan(1, 160, 256)
+    fm = p.featuremap.torch().cpu()
+    e1 = (fm - inter["featuremap"]).abs().max().item() / max(1.0, inter["featuremap"].abs().max().item())
+    n = int(p.roi_count.item())
+    same = n == len(inter["proposal_idx"]) and np.array_equal(p.roi_idx[0, :n].cpu().numpy(), inter["proposal_idx"].astype(np.int32))
+    print(f"proposal bf16x3: featuremap rel err {e1:.2e}; RPN indices identical: {same}")
+    assert e1 < 1e-3
+    rw = RO.synth_weights(1, 2)
+    img2 = (np.random.default_rng(1).random((120, 200, 3)) * 255).astype(np.uint8)
+    box = [20.4, 30.5, 90.6, 150.5]
+    rnet = RefinementNet(rw, 2, precision="bf16x3")
+    rp = rnet.refine(torch.from_numpy(img2).cuda(), torch.tensor([box]).cuda(), max_boxes=2, with_posterior=True)
+    x, crop = RO.make_input(img2, box)
+    with torch.no_grad():
+        lg = RO.deeplab_logits(rw, x, 2)
+    e2 = (rp.logits.torch().cpu()[:1] - lg).abs().max().item() / max(1.0, lg.abs().max().item())
+    rm, rpost = RO.output_layer(lg, crop, 120, 200)
+    e3 = np.abs(rp.posterior[0].cpu().numpy() - rpost).max()
+    print(f"refinement bf16x3: logits rel err {e2:.2e}, posterior abs err {e3:.2e}")
+    assert e2 < 1e-3 and e3 < 1e-3

@@ -20,24 +20,27 @@ SHAPES = [  # name, n, h, w, cin, cout, k, stride, dil
     ("pwc L5 3x3 661->128 B4 16x28", 4, 16, 28, 597, 128, 3, 1, 1),
     ("big 3x3 256->256 M262k", 4, 256, 256, 256, 256, 3, 1, 1),
 ]
+import os
+PRECS = os.environ.get('PRECS', 'fp32').split(',')
 hints = [0] + [int(h) for h in sys.argv[1:]]
 for name, n, h, w, cin, cout, k, s, d in SHAPES:
     x = ops.NHWC.alloc(n, h, w, cin); x.buf.normal_()
     wt = torch.randn(cout, cin, k, k) * 0.05
-    pk = ops.pack_conv(wt, torch.zeros(cout))
     out = ops.NHWC.alloc(n, h, w, cout)
     res = []
-    for hint in hints:
-        try:
-            for _ in range(2): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint)
-        except Exception as e:
-            res.append("  n/a"); continue
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        a.record()
-        for _ in range(reps): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint)
-        b.record(); torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / reps
-        fl = 2.0 * n * h * w * k * k * cin * cout
-        res.append(f"{fl/ms/1e9:6.1f}")
+    for prec in PRECS:
+      pk = ops.pack_conv(wt, torch.zeros(cout), precision=prec)
+      for hint in hints:
+          try:
+              for _ in range(2): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint)
+          except Exception as e:
+              res.append("  n/a"); continue
+          a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          reps = 5
+          a.record()
+          for _ in range(reps): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint)
+          b.record(); torch.cuda.synchronize()
+          ms = a.elapsed_time(b) / reps
+          fl = 2.0 * n * h * w * k * k * cin * cout
+          res.append(f"{fl/ms/1e9:6.1f}")
     print(f"{name:32s} M={n*h*w:7d} K={k*k*cin:5d} N={cout:5d} | " + " ".join(res), flush=True)
