@@ -124,6 +124,70 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   }
 }
 
+// Row-tiled variant for dilation 1: one thread produces TW consecutive output pixels of a row for 4 channels,
+// so the 3 x (TW*stride+2) input window and the 9 weight vectors are loaded once per TW outputs
+// (2.7x fewer load instructions than the per-pixel kernel at TW = 4; the kernel is L2/TA-bound, not HBM-bound).
+template <bool PRE_RELU, int STRIDE, int TW>
+__global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restrict__ in, int in_ps, int n, int h, int w,
+                                                            int c4, const float* __restrict__ wgt,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int out_ps, int ho, int wo, int pt, int pl, int act, int cpad) {
+  constexpr int NCOL = (TW - 1) * STRIDE + 3;
+  const int xt = (wo + TW - 1) / TW;
+  const long total = (long)n * ho * xt * c4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = idx % c4;
+    long t = idx / c4;
+    const int tx = t % xt;
+    t /= xt;
+    const int oy = t % ho, b = t / ho;
+    const int ox0 = tx * TW;
+    float4 k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = *reinterpret_cast<const float4*>(wgt + (long)i * cpad + cg * 4);
+    float4 acc[TW];
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + cg * 4);
+#pragma unroll
+    for (int o = 0; o < TW; ++o) acc[o] = bv;
+    const int ix0 = ox0 * STRIDE - pl;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int iy = oy * STRIDE - pt + j;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      const float* rowp = in + (((long)b * h + iy) * w) * in_ps + cg * 4;
+      float4 v[NCOL];
+#pragma unroll
+      for (int cx = 0; cx < NCOL; ++cx) {
+        const int ix = ix0 + cx;
+        v[cx] = ((unsigned)ix < (unsigned)w) ? *reinterpret_cast<const float4*>(rowp + (long)ix * in_ps)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRE_RELU) {
+          v[cx].x = fmaxf(v[cx].x, 0.f); v[cx].y = fmaxf(v[cx].y, 0.f);
+          v[cx].z = fmaxf(v[cx].z, 0.f); v[cx].w = fmaxf(v[cx].w, 0.f);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < TW; ++o)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float4 a = v[o * STRIDE + i], kk = k[j * 3 + i];
+          acc[o].x += a.x * kk.x; acc[o].y += a.y * kk.y; acc[o].z += a.z * kk.z; acc[o].w += a.w * kk.w;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < TW; ++o) {
+      const int ox = ox0 + o;
+      if (ox >= wo) break;
+      float4 r = acc[o];
+      if (act == PREMVOS_ACT_RELU) {
+        r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(out + (((long)b * ho + oy) * wo + ox) * out_ps + cg * 4) = r;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // tf.image.resize_bilinear (TF1): align_corners=True  src = dst*(in-1)/(out-1);  False (legacy) src = dst*in/out
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, int in_ps, int n, int h,
@@ -292,8 +356,22 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
                  (bias == nullptr || premvos::aligned16(bias)),
              "dwconv3x3: pointers must be 16-byte aligned");
   PV_REQUIRE(act == PREMVOS_ACT_NONE || act == PREMVOS_ACT_RELU, "dwconv3x3: bad activation");
-  const long total = (long)n * ho * wo * (c_pad / 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dilation == 1 && (stride == 1 || stride == 2) && wo >= 8) {   // row-tiled fast path
+    constexpr int TW = 4;
+    const long tot = (long)n * ho * ((wo + TW - 1) / TW) * (c_pad / 4);
+    const dim3 g(grid_for(tot)), b(256);
+#define PV_DW_ROW(PR, ST)                                                                                            \
+  hipLaunchKernelGGL((dwconv3x3_row_kernel<PR, ST, TW>), g, b, 0, s, in, in_ps, n, h, w, c_pad / 4, wgt, bias, out, \
+                     out_ps, ho, wo, pt, pl, act, c_pad)
+    if (pre_relu && stride == 1) PV_DW_ROW(true, 1);
+    else if (pre_relu) PV_DW_ROW(true, 2);
+    else if (stride == 1) PV_DW_ROW(false, 1);
+    else PV_DW_ROW(false, 2);
+#undef PV_DW_ROW
+    return premvos::check_launch("dwconv3x3_row");
+  }
+  const long total = (long)n * ho * wo * (c_pad / 4);
   if (pre_relu)
     hipLaunchKernelGGL(dwconv3x3_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, in_ps, n, h, w, c_pad / 4,
                        wgt, bias, out, out_ps, ho, wo, stride, dilation, pt, pl, act, c_pad);
