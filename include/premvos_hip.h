@@ -87,7 +87,7 @@ typedef struct premvos_conv_desc {
   float* workspace;     /* split-K partial slabs (may be NULL: then never split) */
   int64_t workspace_bytes;
   int32_t precision;    /* PREMVOS_PREC_*; bf16 modes: wgt = bf16 hi [cout_pad][k_pad], k_pad % 32 == 0 */
-  int32_t reserved0;
+  int32_t stage_k;      /* fp32 path: k depth of an LDS stage, 16 or 32 (0 = library default) */
   const void* wgt_lo;   /* BF16X3: bf16 low parts (w - float(hi)), same shape as wgt */
 } premvos_conv_desc;
 

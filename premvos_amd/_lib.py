@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("cin_pad", C.c_int32), ("k_pad", C.c_int32), ("cout_pad", C.c_int32),
         ("act", C.c_int32), ("slope", C.c_float), ("out_mode", C.c_int32), ("cout_ps", C.c_int32),
         ("tile_hint", C.c_int32), ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("precision", C.c_int32), ("reserved0", C.c_int32), ("wgt_lo", C.c_void_p),
+        ("precision", C.c_int32), ("stage_k", C.c_int32), ("wgt_lo", C.c_void_p),
     ]
 
 

@@ -31,22 +31,27 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 namespace {
 
-constexpr int BK = 16;           // k depth per LDS stage
-constexpr int RS = BK + 4;       // LDS row stride (floats): 80 B, keeps b128 reads conflict free
+constexpr int BK = 16;           // k granularity of the packed weights (k_pad % 16 == 0)
 
 // SPLITK: blockIdx.z owns k-steps [z*kt_per, min(KT,(z+1)*kt_per)) and stores its raw partial tile to
 // p.workspace[z][m][ncols]; splitk_reduce_kernel sums the slabs in z order (deterministic) and applies the
 // epilogue.  Used when a layer has too few output tiles to fill 256 CUs (coarse PWC levels, batch-1 RoI/feature maps).
-template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK>
+// KB: k depth of one LDS stage (16 or 32).  Rows are padded by 4 floats (KB+4): 20 and 36 dwords are both 4 x odd,
+// so 16 consecutive rows land on 16 different 16-byte bank slots -> conflict-free ds_read_b128.
+template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
-  constexpr int A_UNITS = BM * 4, B_UNITS = BN * 4;
+  constexpr int RS = KB + 4;
+  constexpr int KU = KB / 4;                   // float4 units per row
+  constexpr int A_UNITS = BM * KU, B_UNITS = BN * KU;
   constexpr int A_PER_T = (A_UNITS + NT - 1) / NT, B_PER_T = (B_UNITS + NT - 1) / NT;
+  constexpr int BUF = (BM + BN) * RS;
 
-  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * RS];
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  float(*lds)[BUF] = reinterpret_cast<float(*)[BUF]>(lds_dyn);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -55,12 +60,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
   // ---- per-thread gather state -------------------------------------------------------------
-  const int j4 = (tid & 3) * 4;  // this thread's float4 column inside the 16-deep stage
+  const int j4 = (tid % KU) * 4;  // this thread's float4 column inside the KB-deep stage
   const float* rowbase[A_PER_T];
   int iy0[A_PER_T], ix0[A_PER_T];
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
-    const int row = (tid >> 2) + i * (NT / 4);
+    const int row = (tid / KU) + i * (NT / KU);
     const int m = m0 + row;
     const bool ok = (row < BM) && (m < M);
     const int mm = ok ? m : 0;
@@ -71,12 +76,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     iy0[i] = ok ? oy * p.sh - p.pt : -(1 << 28);  // invalid rows fail the bounds test below
     ix0[i] = ox * p.sw - p.pl;
   }
-  const int KT_all = p.k_pad / BK;
+  const int KT_all = (p.k_pad + KB - 1) / KB;          // KB = 32 on a k_pad % 32 == 16 matrix: last half stage is zero
   const int kt_begin = SPLITK ? blockIdx.z * kt_per : 0;
   const int kt_end = SPLITK ? (kt_begin + kt_per < KT_all ? kt_begin + kt_per : KT_all) : KT_all;
   int kh, kw, c;
   {
-    const int k0 = kt_begin * BK + j4;
+    const int k0 = kt_begin * KB + j4;
     const int tap = k0 / p.cin_pad;
     c = k0 - tap * p.cin_pad;
     kh = tap / p.kw;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
   bool wok[B_PER_T];
 #pragma unroll
   for (int i = 0; i < B_PER_T; ++i) {
-    const int row = (tid >> 2) + i * (NT / 4);
+    const int row = (tid / KU) + i * (NT / KU);
     wok[i] = (row < BN) && (n0 + row < p.cout_pad);
     wrow[i] = p.wgt + (long)(wok[i] ? n0 + row : 0) * p.k_pad + j4;
   }
@@ -104,8 +109,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i)
-      rb[i] = wok[i] ? *reinterpret_cast<const float4*>(wrow[i] + kt * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
-    c += BK;
+      rb[i] = (wok[i] && kt * KB + j4 < p.k_pad) ? *reinterpret_cast<const float4*>(wrow[i] + kt * KB)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    c += KB;
     while (c >= p.cin_pad) {
       c -= p.cin_pad;
       if (++kw == p.kw) { kw = 0; ++kh; }
@@ -116,12 +122,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     float* b = &lds[buf][BM * RS];
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
-      const int row = (tid >> 2) + i * (NT / 4);
+      const int row = (tid / KU) + i * (NT / KU);
       if (A_UNITS % NT == 0 || row < BM) *reinterpret_cast<float4*>(a + row * RS + j4) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
-      const int row = (tid >> 2) + i * (NT / 4);
+      const int row = (tid / KU) + i * (NT / KU);
       if (B_UNITS % NT == 0 || row < BN) *reinterpret_cast<float4*>(b + row * RS + j4) = rb[i];
     }
   };
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     const float* a = &lds[buf][wm0 * RS + frag_off];
     const float* b = &lds[buf][(BM + wn0) * RS + frag_off];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < KB / 8; ++h) {
       float4 af[MT], bf[NTL];
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
@@ -259,25 +265,53 @@ int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipS
 namespace {
 
 // how many k-slices a layer is cut into (1 = no split): aim for >= ~3 workgroups per CU
-inline int pick_splits(const premvos_conv_desc& d, int bm, int bn) {
+inline int pick_splits(const premvos_conv_desc& d, int bm, int bn, int kb) {
   if (d.split_k > 0) return d.split_k;
   if (d.split_k < 0) return 1;
   const long tiles = (long)premvos::cdiv(d.n * d.ho * d.wo, bm) * premvos::cdiv(d.cout, bn);
-  const int KT = d.k_pad / BK;
-  if (tiles >= 384 || KT < 16) return 1;
+  const int KT = premvos::cdiv(d.k_pad, kb);
+  if (tiles >= 384 || KT * kb < 256) return 1;
   long s = (768 + tiles - 1) / tiles;
-  if (s > KT / 8) s = KT / 8;
+  if (s > KT * kb / 128) s = KT * kb / 128;
   if (s > 32) s = 32;
   return s < 2 ? 1 : (int)s;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <typename K>
+inline void allow_lds(K kernel, int bytes) {   // > 64 KB of LDS per workgroup needs the attribute
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// stage depth: 32 halves the barriers per MFMA (helps long-K MFMA-bound layers) at 1.8x the LDS per workgroup
+// Measured on MI355X (tools/conv_bench.py): 32-deep stages are +5..28 % on long-K layers whose tile count fills
+// whole waves of 2 workgroups/CU (72 KB LDS), and -8..20 % where 16-deep stages fit one more workgroup per CU
+// (40 KB LDS -> 3/CU) and thereby avoid a second, mostly empty wave.  Model: time ~ waves(tiles, slots) / f(K).
+inline int pick_kb(const premvos_conv_desc& d) {
+  if (d.stage_k == 16 || d.stage_k == 32) return d.stage_k;
+  const long M = (long)d.n * d.ho * d.wo;
+  const long t128 = ((M + 127) / 128) * ((d.cout + 127) / 128);
+  if (t128 < 512 || d.cout <= 96) return 16;            // pick_tile would not choose the 128x128 tile
+  const int K = d.kh * d.kw * d.cin_pad;
+  const double f = K >= 1024 ? 1.10 : K >= 512 ? 1.03 : 0.93;
+  auto q = [](long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
+  return f * q(t128, 512) > q(t128, 768) ? 32 : 16;
+}
+
+template <int BM, int BN, int WM, int WN, int KB = 16>
 int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   const int M = d.n * d.ho * d.wo;
   dim3 grid(premvos::cdiv(M, BM), premvos::cdiv(d.cout, BN));
   dim3 block(64 * WM * WN);
-  int splits = pick_splits(d, BM, BN);
-  const int KT = d.k_pad / BK;
+  constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>, LDS_BYTES);
+    allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>, LDS_BYTES);
+    allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>, LDS_BYTES);
+    attr_done = true;
+  }
+  int splits = pick_splits(d, BM, BN, KB);
+  const int KT = premvos::cdiv(d.k_pad, KB);
   if (splits > 1) {
     const int kt_per = premvos::cdiv(KT, splits);
     splits = premvos::cdiv(KT, kt_per);
@@ -285,7 +319,7 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     const long need = (long)splits * M * ncols * sizeof(float);
     if (splits > 1 && d.workspace != nullptr && (long)d.workspace_bytes >= need) {
       grid.z = splits;
-      hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, d, kt_per);
+      hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per);
       int rc = premvos::check_launch("conv_igemm_f32(split-k)");
       if (rc) return rc;
       return premvos::launch_splitk_reduce(d, splits, ncols, s);
@@ -293,17 +327,18 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     if (d.split_k > 0) return premvos::fail(PREMVOS_EINVAL, "conv2d: split_k=%d needs %ld workspace bytes", d.split_k, need);
   }
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, d, 0);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>), grid, block, LDS_BYTES, s, d, 0);
   else
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, d, 0);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>), grid, block, LDS_BYTES, s, d, 0);
   return premvos::check_launch("conv_igemm_f32");
 }
 
 template <int BM, int BN, int WM, int WN>
 long ws_cfg(const premvos_conv_desc& d) {
-  int splits = pick_splits(d, BM, BN);
+  const int kb = pick_kb(d);
+  int splits = pick_splits(d, BM, BN, kb);
   if (splits <= 1) return 0;
-  const int KT = d.k_pad / BK;
+  const int KT = premvos::cdiv(d.k_pad, kb);
   const int kt_per = premvos::cdiv(KT, splits);
   splits = premvos::cdiv(KT, kt_per);
   if (splits <= 1) return 0;
@@ -353,6 +388,14 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   if (d.precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16(d, s);
   int bm, bn;
   pick_tile(d, &bm, &bn);
+  if (pick_kb(d) == 32) {
+    switch ((bm << 16) | bn) {
+      case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2, 32>(d, s);
+      case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2, 32>(d, s);
+      case (64 << 16) | 128: return launch_cfg<64, 128, 2, 2, 32>(d, s);
+      default: break;   // other tiles only exist with 16-deep stages
+    }
+  }
   switch ((bm << 16) | bn) {
     case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2>(d, s);
     case (128 << 16) | 96: return launch_cfg<128, 96, 4, 1>(d, s);

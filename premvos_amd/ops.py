@@ -127,7 +127,8 @@ def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
 
 
 def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1), pad=(0, 0),
-              act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None, tile_hint: int = 0, split_k: int = 0) -> ConvDesc:
+              act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None, tile_hint: int = 0, split_k: int = 0,
+              stage_k: int = 0) -> ConvDesc:
     """Build the descriptor (validated again on the C side).  ``pad`` = (top, left); the output
     size comes from ``out`` so asymmetric bottom/right padding is implicit."""
     assert x.c == pk.cin, (x.c, pk.cin)
@@ -155,6 +156,7 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     d.act, d.slope = act, slope
     d.tile_hint = tile_hint
     d.split_k = split_k
+    d.stage_k = stage_k
     d.workspace, d.workspace_bytes = None, 0
     d.precision = pk.precision
     d.wgt_lo = pk.wgt_lo.data_ptr() if pk.wgt_lo is not None else None

@@ -23,6 +23,7 @@ SHAPES = [  # name, n, h, w, cin, cout, k, stride, dil
 import os
 PRECS = os.environ.get('PRECS', 'fp32').split(',')
 hints = [0] + [int(h) for h in sys.argv[1:]]
+STAGES = [int(x) for x in os.environ.get('STAGES', '0').split(',')]
 for name, n, h, w, cin, cout, k, s, d in SHAPES:
     x = ops.NHWC.alloc(n, h, w, cin); x.buf.normal_()
     wt = torch.randn(cout, cin, k, k) * 0.05
@@ -30,15 +31,15 @@ for name, n, h, w, cin, cout, k, s, d in SHAPES:
     res = []
     for prec in PRECS:
       pk = ops.pack_conv(wt, torch.zeros(cout), precision=prec)
-      for hint in hints:
+      for hint, stage in [(h_, s_) for h_ in hints for s_ in STAGES]:
           try:
-              for _ in range(2): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint)
+              for _ in range(2): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint, stage_k=stage)
           except Exception as e:
               res.append("  n/a"); continue
           a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
           reps = 5
           a.record()
-          for _ in range(reps): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint)
+          for _ in range(reps): ops.conv2d(x, pk, out, pad=(d * (k // 2),) * 2, dilation=(d, d), act=ops.ACT_RELU, tile_hint=hint, stage_k=stage)
           b.record(); torch.cuda.synchronize()
           ms = a.elapsed_time(b) / reps
           fl = 2.0 * n * h * w * k * k * cin * cout
