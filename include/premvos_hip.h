@@ -35,6 +35,7 @@ extern "C" {
 #define PREMVOS_ACT_NONE 0
 #define PREMVOS_ACT_RELU 1
 #define PREMVOS_ACT_LEAKY 2 /* x > 0 ? x : slope * x   (nn.LeakyReLU(0.1), PWCNet.py:28) */
+#define PREMVOS_ACT_SIGMOID 3 /* 1/(1+exp(-x))   (mask head, proposal_net/train.py:305) */
 
 /* arithmetic of the dense-conv MFMA pipe (activations and outputs are fp32 in HBM in every mode) */
 #define PREMVOS_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products (the parity / default bench mode)        */

@@ -152,6 +152,11 @@ def synth_weights(seed: int = 0, num_blocks=RESNET_NUM_BLOCK) -> Dict[str, objec
     w["fastrcnn/class/b"] = torch.randn(NUM_CLASS, generator=_g("frcb", seed)) * 0.1
     w["fastrcnn/box/W"] = torch.randn(((NUM_CLASS - 1) * 4, 2048), generator=_g("frb", seed)) * 0.05
     w["fastrcnn/box/b"] = torch.randn((NUM_CLASS - 1) * 4, generator=_g("frbb", seed)) * 0.1
+    # mask head (model.py:494-509): Deconv2D 2x2 s2 -> 256 (+ReLU), Conv2D 1x1 -> NUM_CLASS-1.  [cin,cout,kh,kw] here.
+    w["maskrcnn/deconv/W"] = torch.randn((2048, 256, 2, 2), generator=_g("mdc", seed)) * math.sqrt(2.0 / 2048)
+    w["maskrcnn/deconv/b"] = torch.randn(256, generator=_g("mdcb", seed)) * 0.05
+    w["maskrcnn/conv/W"] = _conv_w("maskrcnn/conv/W", NUM_CLASS - 1, 256, 1, seed, gain=8.0)
+    w["maskrcnn/conv/b"] = torch.randn(NUM_CLASS - 1, generator=_g("mcb", seed)) * 0.3
     w["secondclassification/class/W"] = torch.randn((SECOND_NUM_CLASS, 2048), generator=_g("sc", seed)) * 0.05
     w["secondclassification/class/b"] = torch.randn(SECOND_NUM_CLASS, generator=_g("scb", seed)) * 0.1
     return w
@@ -360,6 +365,31 @@ def fastrcnn_tail(cls_logits: np.ndarray, box_logits: np.ndarray, proposals: np.
     order = sorted(sel.tolist(), key=lambda i: (-float(p[i]), i))[:RESULTS_PER_IM]
     order = np.array(order, np.int64)
     return dec[order], p[order], np.ones(len(order), np.int64), order
+
+
+def maskrcnn_masks(w, fm: torch.Tensor, final_boxes: np.ndarray, num_block=RESNET_NUM_BLOCK[3]) -> np.ndarray:
+    """train.py:297-309 + model.py:494-509 (MODE_MASK): RoIAlign on the FINAL boxes -> conv5 -> deconv 2x2 s2 + ReLU
+    -> 1x1 -> sigmoid.  Returns [M,14,14] float32 (the single foreground category)."""
+    if final_boxes.shape[0] == 0:
+        return np.zeros((0, 14, 14), np.float32)
+    roi = roi_align(fm, final_boxes * np.float32(1.0 / ANCHOR_STRIDE), 14)
+    f5 = resnet_conv5(w, roi, num_block)
+    l = F.relu(F.conv_transpose2d(f5, w["maskrcnn/deconv/W"], w["maskrcnn/deconv/b"], stride=2))
+    l = F.conv2d(l, w["maskrcnn/conv/W"], w["maskrcnn/conv/b"])
+    return torch.sigmoid(l[:, 0]).numpy()
+
+
+def fill_full_mask(box: np.ndarray, mask: np.ndarray, shape) -> np.ndarray:
+    """eval.py:35-58: paste a 14x14 mask into the frame (cv2.resize float INTER_LINEAR, > 0.5)."""
+    from . import cv_resize_oracle as R
+    x0, y0 = list(map(int, box[:2] + 0.5))
+    x1, y1 = list(map(int, box[2:] - 0.5))
+    x1, y1 = max(x0, x1), max(y0, y1)
+    wd, ht = x1 + 1 - x0, y1 + 1 - y0
+    m = (R.resize_linear_f32(np.ascontiguousarray(mask, np.float32), wd, ht) > 0.5).astype("uint8")
+    ret = np.zeros(shape, dtype="uint8")
+    ret[y0:y1 + 1, x0:x1 + 1] = m[:max(0, min(ht, shape[0] - y0)), :max(0, min(wd, shape[1] - x0))]
+    return ret
 
 
 def model_forward(w, resized_img_bgr: np.ndarray, num_blocks=RESNET_NUM_BLOCK, intermediates=False):

@@ -15,7 +15,7 @@ from . import build as _build
 
 _LIB = None
 
-ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NHWC, OUT_PIXSHUF2 = 0, 1
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
         if (p.res != nullptr) v += p.res[(long)m * p.res_ps + col];
         if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
         else if (p.act == PREMVOS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+        else if (p.act == PREMVOS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
         if constexpr (PIXSHUF) {
           const int hw = p.ho * p.wo;
           const int n = m / hw, rem = m - n * hw;

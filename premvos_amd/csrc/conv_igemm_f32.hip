@@ -205,6 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
         if (p.res != nullptr) v += p.res[(long)m * p.res_ps + col];
         if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
         else if (p.act == PREMVOS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+        else if (p.act == PREMVOS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
         if constexpr (PIXSHUF) {
           const int hw = p.ho * p.wo;
           const int n = m / hw, rem = m - n * hw;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const premvos_conv_d
     if (p.res != nullptr) v += p.res[(long)m * p.res_ps + col];
     if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
     else if (p.act == PREMVOS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+        else if (p.act == PREMVOS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
     if constexpr (PIXSHUF) {
       const int hw = p.ho * p.wo;
       const int n = m / hw, rem = m - n * hw;
@@ -377,7 +379,7 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   PV_REQUIRE(d.out_ps >= (d.out_mode == PREMVOS_OUT_PIXSHUF2 ? d.cout_ps : d.cout), "conv2d: out_ps < cout");
   PV_REQUIRE(d.res == nullptr || d.res_ps >= d.cout, "conv2d: res_ps < cout");
   PV_REQUIRE(d.res == nullptr || d.out_mode == PREMVOS_OUT_NHWC, "conv2d: residual needs NHWC output");
-  PV_REQUIRE(d.act >= PREMVOS_ACT_NONE && d.act <= PREMVOS_ACT_LEAKY, "conv2d: bad activation");
+  PV_REQUIRE(d.act >= PREMVOS_ACT_NONE && d.act <= PREMVOS_ACT_SIGMOID, "conv2d: bad activation");
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
     PV_REQUIRE(d.cout_ps > 0 && d.cout == 4 * d.cout_ps, "conv2d: PIXSHUF2 needs cout == 4*cout_ps");
   else

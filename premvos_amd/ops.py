@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, OUT_NHWC, OUT_PIXSHUF2, ConvDesc  # noqa: F401
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, OUT_NHWC, OUT_PIXSHUF2, ConvDesc  # noqa: F401
 
 
 def _r(x: int, m: int) -> int:
@@ -122,6 +122,20 @@ def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
                     w3[ph * cout:(ph + 1) * cout, :, dy + 1, dx + 1] = w[:, :, ky, kx].t()
     b4 = None if bias is None else bias.detach().to(torch.float32).cpu().repeat(4)
     pk = pack_conv(w3, b4, device, precision=precision)
+    pk.cout_ps = cout
+    return pk
+
+
+def pack_deconv2x2s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
+                     precision: str = "fp32") -> PackedConv:
+    """ConvTranspose2d(k=2,s=2) (tensorpack Deconv2D(…, 2, stride=2), proposal_net/model.py:507): the taps do not
+    overlap, so it is a 1x1 conv with 4*cout phase outputs (phase = 2*ky+kx writes out[2y+ky][2x+kx])."""
+    w = weight.detach().to(torch.float32).cpu()
+    cin, cout, kh, kw = w.shape
+    assert (kh, kw) == (2, 2)
+    w1 = w.permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1).contiguous()
+    b4 = None if bias is None else bias.detach().to(torch.float32).cpu().repeat(4)
+    pk = pack_conv(w1, b4, device, precision=precision)
     pk.cout_ps = cout
     return pk
 

@@ -56,7 +56,8 @@ class OfflinePredictor:
             img = np.clip(np.rint(img), 0, 255).astype(np.uint8)     # the pipeline only ever feeds uint8 frames
         t = torch.from_numpy(img).unsqueeze(0).to(self.net.device)
         p = self.net.run_resized(t)
-        return self.net.outputs(p, 0)[:6]
+        out = self.net.outputs(p, 0)[:6]
+        return out + (self.net.masks(p, 0),) if self.net.mode_mask else out   # + 'final_masks' (train.py:58-59)
 
 
 class ProposalStage:
@@ -101,7 +102,38 @@ class ProposalStage:
 
     def detections(self, i: int, orig_hw) -> List[SecondDetectionResult]:
         boxes, probs, labels, post, sl, sp, _ = self.net.outputs(self.plan, i)
-        return _to_results(boxes, probs, labels, post, sl, sp, self.scale, orig_hw)
+        masks = self.net.masks(self.plan, i) if self.net.mode_mask else None
+        return _to_results(boxes, probs, labels, post, sl, sp, self.scale, orig_hw, masks)
+
+
+def _cv_resize_f32(img: np.ndarray, dst_w: int, dst_h: int) -> np.ndarray:
+    """cv2.resize(float32, INTER_LINEAR) on the host (eval.py:54 runs it on the CPU too): half-pixel centres,
+    edge clamp, horizontal then vertical lerp (OpenCV imgproc resize.cpp)."""
+    def co(dst, src):
+        f = ((np.arange(dst, dtype=np.float64) + 0.5) * (1.0 / (float(dst) / float(src))) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo, hi = s < 0, s >= src - 1
+        f[lo], s[lo] = 0.0, 0
+        f[hi], s[hi] = 0.0, src - 1
+        return s, np.minimum(s + 1, src - 1), f
+    h, w = img.shape
+    x0, x1, fx = co(dst_w, w)
+    y0, y1, fy = co(dst_h, h)
+    rows = img[:, x0] * (np.float32(1) - fx)[None, :] + img[:, x1] * fx[None, :]
+    return (rows[y0] * (np.float32(1) - fy)[:, None] + rows[y1] * fy[:, None]).astype(np.float32)
+
+
+def fill_full_mask(box, mask, shape) -> np.ndarray:
+    """eval.py:35-58."""
+    x0, y0 = list(map(int, box[:2] + 0.5))
+    x1, y1 = list(map(int, box[2:] - 0.5))
+    x1, y1 = max(x0, x1), max(y0, y1)
+    w, h = x1 + 1 - x0, y1 + 1 - y0
+    m = (_cv_resize_f32(np.ascontiguousarray(mask, np.float32), w, h) > 0.5).astype("uint8")
+    ret = np.zeros(shape, dtype="uint8")
+    ret[y0:y1 + 1, x0:x1 + 1] = m[:max(0, min(h, shape[0] - y0)), :max(0, min(w, shape[1] - x0))]
+    return ret
 
 
 def clip_boxes(boxes: np.ndarray, shape) -> np.ndarray:
@@ -115,10 +147,11 @@ def clip_boxes(boxes: np.ndarray, shape) -> np.ndarray:
     return boxes.reshape(orig_shape)
 
 
-def _to_results(boxes, probs, labels, posteriors, second_labels, second_posteriors, scale, orig_shape):
+def _to_results(boxes, probs, labels, posteriors, second_labels, second_posteriors, scale, orig_shape, masks=None):
     boxes = boxes / scale                      # eval.py:93
     boxes = clip_boxes(boxes, orig_shape)      # eval.py:94
-    return [SecondDetectionResult(*a) for a in zip(boxes, probs, labels, posteriors, [None] * len(boxes),
+    full = [None] * len(boxes) if masks is None else [fill_full_mask(b, m, orig_shape) for b, m in zip(boxes, masks)]
+    return [SecondDetectionResult(*a) for a in zip(boxes, probs, labels, posteriors, full,
                                                    second_labels, second_posteriors, [None] * len(boxes))]
 
 
@@ -151,7 +184,11 @@ def convert_results_to_json(results, img_idx=None) -> List[dict]:
         box = np.array(r.box)
         box[2] -= box[0]
         box[3] -= box[1]
-        img_res.append({"bbox": list(map(lambda x: float(round(x, 1)), box)), "score": float(round(r.score, 2))})
+        res = {"bbox": list(map(lambda x: float(round(x, 1)), box)), "score": float(round(r.score, 2))}
+        if r.mask is not None:                 # train.py:419-425 (MODE_MASK only)
+            from .. import rle
+            res["segmentation"] = rle.encode(r.mask)
+        img_res.append(res)
     return img_res
 
 

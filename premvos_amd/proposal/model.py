@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from ..ops import ACT_NONE, ACT_RELU, NHWC
+from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, NHWC
 
 RESNET_NUM_BLOCK = (3, 4, 23, 3)           # config.py:61
 ANCHOR_STRIDE = 16
@@ -98,26 +98,26 @@ class _Plan:
                                                0.0, _lib.current_stream()), "maxpool")
         steps.append(("maxpool", pool))
 
-        def group(x: NHWC, g: int, feat: int, count: int, stride: int) -> NHWC:
+        def group(x: NHWC, g: int, feat: int, count: int, stride: int, tag: str = "") -> NHWC:
             for i in range(count):
                 p = f"group{g}/block{i}"
                 s = stride if i == 0 else 1
                 t1 = alloc(x.n, x.h, x.w, feat)
-                conv(x, p + "/conv1", t1, act=ACT_RELU)
+                conv(x, p + "/conv1", t1, uid=tag + p + "/conv1", act=ACT_RELU)
                 if s == 2:        # pad [0,1] + VALID stride 2  (basemodel.py:54-56)
                     ho, wo = ops.out_size(x.h, 3, 2, 0, 1), ops.out_size(x.w, 3, 2, 0, 1)
                     t2 = alloc(x.n, ho, wo, feat)
-                    conv(t1, p + "/conv2", t2, stride=(2, 2), pad=(0, 0), act=ACT_RELU)
+                    conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", stride=(2, 2), pad=(0, 0), act=ACT_RELU)
                 else:
                     t2 = alloc(x.n, x.h, x.w, feat)
-                    conv(t1, p + "/conv2", t2, pad=(1, 1), act=ACT_RELU)
+                    conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", pad=(1, 1), act=ACT_RELU)
                 if p + "/convshortcut" in P:   # 1x1 stride s on x[:, :, :-1, :-1] == reading pixel (s*oy, s*ox)
                     sc = alloc(x.n, t2.h, t2.w, feat * 4)
-                    conv(x, p + "/convshortcut", sc, stride=(s, s))
+                    conv(x, p + "/convshortcut", sc, uid=tag + p + "/convshortcut", stride=(s, s))
                 else:
                     sc = x
                 y = alloc(x.n, t2.h, t2.w, feat * 4)
-                conv(t2, p + "/conv3", y, res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
+                conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
                 x = y
             return x
 
@@ -178,6 +178,22 @@ class _Plan:
                 self.final_boxes.data_ptr(), self.final_probs.data_ptr(), self.final_idx.data_ptr(),
                 self.final_count.data_ptr(), _lib.current_stream()), "frcnn_tail")
         steps.append(("frcnn_tail", tail))
+
+        # mask head (train.py:297-309, model.py:494-509) -- OFF in the shipped --forward pipeline (train.py:636-637)
+        self.final_masks: Optional[NHWC] = None
+        if net.mode_mask:
+            mroi = alloc(b * M, 14, 14, 1024)
+
+            def malign(o=mroi):
+                _lib.check(lib.premvos_roi_align_f32(fm.ptr, fm.ps, b, fh, fw, 1024, self.final_boxes.data_ptr(),
+                                                     self.final_count.data_ptr(), M, 1.0 / ANCHOR_STRIDE, 14, o.ptr,
+                                                     o.ps, _lib.current_stream()), "roi_align(mask)")
+            steps.append(("roi_align_mask", malign))
+            mf5 = group(mroi, 3, 512, nb[3], 2, tag="mask:")   # the SAME conv5 weights (auto_reuse_variable_scope)
+            up = alloc(b * M, 14, 14, 256)
+            conv(mf5, "maskrcnn/deconv", up, act=ACT_RELU)
+            self.final_masks = alloc(b * M, 14, 14, NUM_CLASS - 1)
+            conv(up, "maskrcnn/conv", self.final_masks, act=ACT_SIGMOID)
         self.steps, self.buffers = steps, keep
         self.ws_splitk = ops.assign_workspace(self.descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -206,8 +222,10 @@ class ProposalNet:
     beta, mean, var), 'rpn/{conv0,class,box}/{W,b}', 'fastrcnn/{class,box}/{W,b}', 'secondclassification/class/{W,b}'."""
 
     def __init__(self, weights: Dict[str, object], num_blocks: Sequence[int] = RESNET_NUM_BLOCK,
-                 device: str = "cuda", use_graph: bool = True, precision: Optional[str] = None):
+                 device: str = "cuda", use_graph: bool = True, precision: Optional[str] = None,
+                 mode_mask: bool = False):
         _lib.require_gpu()
+        self.mode_mask = mode_mask
         self.precision = prec = precision or ops.default_precision()
         self.device, self.use_graph, self.num_blocks = device, use_graph, tuple(num_blocks)
         self.packed: Dict[str, ops.PackedConv] = {}
@@ -223,6 +241,10 @@ class ProposalNet:
         hw = torch.cat([w["fastrcnn/class/W"], w["fastrcnn/box/W"], w["secondclassification/class/W"]], 0)
         hb = torch.cat([w["fastrcnn/class/b"], w["fastrcnn/box/b"], w["secondclassification/class/b"]], 0)
         self.packed["heads"] = ops.pack_conv(hw.view(hw.shape[0], hw.shape[1], 1, 1), hb, device, precision=prec)
+        if mode_mask:
+            self.packed["maskrcnn/deconv"] = ops.pack_deconv2x2s2(w["maskrcnn/deconv/W"], w["maskrcnn/deconv/b"], device,
+                                                                  precision=prec)
+            self.packed["maskrcnn/conv"] = ops.pack_conv(w["maskrcnn/conv/W"], w["maskrcnn/conv/b"], device, precision=prec)
 
     def plan(self, b: int, h: int, w: int) -> _Plan:
         key = (b, h, w)
@@ -266,3 +288,9 @@ class ProposalNet:
         second_final_posterior = sec_probs[np.zeros((n,), np.int64)] if n else np.zeros((0, SECOND_NUM_CLASS), np.float32)
         second_final_labels = (final_posterior.argmax(-1) + 1) if n else np.zeros((0,), np.int64)
         return boxes, probs, labels, final_posterior, second_final_labels, second_final_posterior, idx
+
+    def masks(self, p: _Plan, i: int = 0) -> np.ndarray:
+        """'final_masks' of get_model_output_names() when MODE_MASK: [n,14,14] sigmoid probabilities."""
+        n = int(p.final_count[i].item())
+        m = p.final_masks.buf.view(p.b, RESULTS_PER_IM, 14, 14, -1)[i, :n, :, :, 0]
+        return m.cpu().numpy()

@@ -186,3 +186,27 @@ def test_detect_one_image_and_json(tmp_path):
         assert abs(a["score"] - b["score"]) <= 0.011
         assert np.abs(np.array(a["bbox"]) - np.array(b["bbox"])).max() <= 0.11
         assert all(isinstance(v, float) for v in a["bbox"])
+
+
+def test_mask_head_mode_mask():
+    """the mask branch (only with MODE_MASK; --forward switches it off, train.py:636-637)."""
+    from premvos_amd import rle
+    from premvos_amd.proposal import OfflinePredictor, ProposalNet, convert_results_to_json, detect_one_image
+    w = P.synth_weights(4, SMALL)
+    img = np.random.default_rng(4).integers(0, 256, (160, 256, 3), dtype=np.uint8)
+    (fb, fp, fl, fi), inter = P.model_forward(w, img, SMALL, intermediates=True)
+    ref_masks = P.maskrcnn_masks(w, inter["featuremap"], fb, SMALL[3])
+    net = ProposalNet(w, SMALL, mode_mask=True)
+    out = OfflinePredictor(net)(img)
+    assert len(out) == 7 and out[6].shape == ref_masks.shape == (len(fb), 14, 14)
+    assert np.abs(out[6] - ref_masks).max() < 2e-3
+    # host paste (eval.py:35-58) + JSON with RLE (train.py:419-425)
+    res = detect_one_image(img, OfflinePredictor(net))
+    js = convert_results_to_json(res)
+    assert all("segmentation" in j and j["segmentation"]["size"] == [160, 256] for j in js)
+    assert len(js) == len(res) > 0 and res[0].mask.shape == (160, 256)
+    assert np.array_equal(rle.decode(js[0]["segmentation"]), res[0].mask)
+    # the host paste itself, on identical inputs, equals the oracle's restatement of eval.py:35-58
+    from premvos_amd.proposal.driver import fill_full_mask
+    for box, m in zip(fb.astype(np.float64), ref_masks):
+        assert np.array_equal(fill_full_mask(box, m, (160, 256)), P.fill_full_mask(box, m, (160, 256)))
