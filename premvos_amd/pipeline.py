@@ -31,12 +31,15 @@ class FramePipeline:
         self.prop_s = ProposalStage(prop_specific, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True,
                                     precision=precision)
         self.refine = RefinementNet(refine_w, num_middle, device, precision=precision)
+        # a second refinement workspace so two frames of a batch can be in flight on different streams
+        import os
+        self.n_refine_lanes = min(batch, int(os.environ.get("PREMVOS_REFINE_LANES", "2"))) if concurrent else 1
         self.masks: Optional[torch.Tensor] = None
         self.conf: Optional[torch.Tensor] = None
         # the four stages of a frame are independent: each replays its HIP graph on its own stream so that the
         # partial last wave of one kernel is filled by another stage's workgroups
         self.concurrent = concurrent
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(4)] if concurrent else None
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(3 + self.n_refine_lanes)] if concurrent else None
 
     def step(self, frames_a: torch.Tensor, frames_b: torch.Tensor, boxes_y0x0y1x1: torch.Tensor):
         """frames_*: uint8 RGB [B,H,W,3] (frame t and t+1); boxes: float [B,P,4] to refine on frame t.
@@ -45,9 +48,9 @@ class FramePipeline:
         if self.masks is None or self.masks.shape != (B, self.P, H, W):
             self.masks = torch.zeros((B, self.P, H, W), dtype=torch.uint8, device=self.device)
             self.conf = torch.zeros((B, self.P), dtype=torch.float32, device=self.device)
-        def refine_all():
-            for i in range(B):
-                p = self.refine.refine(frames_a[i], boxes_y0x0y1x1[i], max_boxes=self.P)
+        def refine_all(lane=0, lanes=1):
+            for i in range(lane, B, lanes):
+                p = self.refine.refine(frames_a[i], boxes_y0x0y1x1[i], max_boxes=self.P, lane=lane)
                 self.masks[i].copy_(p.mask)
                 self.conf[i].copy_(p.conf)
 
@@ -59,8 +62,10 @@ class FramePipeline:
         else:
             cur = torch.cuda.current_stream()
             res = {}
-            jobs = (("r", refine_all), ("g", lambda: self.prop_g.run(frames_a)),
-                    ("s", lambda: self.prop_s.run(frames_a)), ("f", lambda: self.flow.run(frames_a, frames_b)))
+            L = self.n_refine_lanes
+            jobs = [("r%d" % l, (lambda l=l: refine_all(l, L))) for l in range(L)]
+            jobs += [("g", lambda: self.prop_g.run(frames_a)), ("s", lambda: self.prop_s.run(frames_a)),
+                     ("f", lambda: self.flow.run(frames_a, frames_b))]
             for st, (k, fn) in zip(self.streams, jobs):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
@@ -79,6 +84,6 @@ class FramePipeline:
                                   ("prop_g", self.prop_g.steps, self.prop_g.plan.flops),
                                   ("prop_s", self.prop_s.steps, self.prop_s.plan.flops)):
             out += [(tag, n, f, flops[n]) for n, f in steps if n.startswith("conv:")]
-        rp = self.refine.plan(self.P, *self.masks.shape[2:])
+        rp = self.refine.plan(self.P, *self.masks.shape[2:], False, 0)
         out += [("refine", n, f, rp.flops[n] * self.batch) for n, f in rp.steps if n.startswith("conv:")]
         return out

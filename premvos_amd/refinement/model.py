@@ -268,8 +268,9 @@ class RefinementNet:
                 else:
                     self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device, precision=prec)
 
-    def plan(self, P: int, H: int, W: int, with_posterior: bool = False) -> _Plan:
-        key = (P, H, W, with_posterior)
+    def plan(self, P: int, H: int, W: int, with_posterior: bool = False, lane: int = 0) -> _Plan:
+        """``lane`` selects an independent workspace (same weights) so several frames can be in flight."""
+        key = (P, H, W, with_posterior, lane)
         if key not in self._plans:
             p = _Plan(self, P, H, W, with_posterior)
             if self.use_graph:
@@ -278,14 +279,14 @@ class RefinementNet:
         return self._plans[key]
 
     def refine(self, frame_rgb: torch.Tensor, boxes_y0x0y1x1: torch.Tensor, max_boxes: Optional[int] = None,
-               with_posterior: bool = False) -> _Plan:
+               with_posterior: bool = False, lane: int = 0) -> _Plan:
         """frame uint8 [H,W,3] RGB, boxes float [n,4] (y0,x0,y1,x1).  Results stay in the returned plan:
         ``mask`` uint8 [P,H,W], ``conf`` [P], ``posterior`` (optional), valid for the first n entries."""
         n = boxes_y0x0y1x1.shape[0]
         P = max_boxes or max(n, 1)
         assert n <= P
         H, W, _ = frame_rgb.shape
-        p = self.plan(P, H, W, with_posterior)
+        p = self.plan(P, H, W, with_posterior, lane)
         p.frame.copy_(frame_rgb)
         p.boxes.zero_()
         if n:
