@@ -7,6 +7,7 @@ gather (premvos_amd.parallel).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -32,13 +33,12 @@ class FramePipeline:
                                     precision=precision)
         self.refine = RefinementNet(refine_w, num_middle, device, precision=precision)
         # a second refinement workspace so two frames of a batch can be in flight on different streams
-        import os
         self.n_refine_lanes = min(batch, int(os.environ.get("PREMVOS_REFINE_LANES", "2"))) if concurrent else 1
         self.masks: Optional[torch.Tensor] = None
         self.conf: Optional[torch.Tensor] = None
         # the four stages of a frame are independent: each replays its HIP graph on its own stream so that the
         # partial last wave of one kernel is filled by another stage's workgroups
-        self.concurrent = concurrent
+        self.concurrent = concurrent = concurrent and os.environ.get("PREMVOS_PIPELINE_SERIAL") != "1"
         self.streams = [torch.cuda.Stream(device=device) for _ in range(3 + self.n_refine_lanes)] if concurrent else None
 
     def step(self, frames_a: torch.Tensor, frames_b: torch.Tensor, boxes_y0x0y1x1: torch.Tensor):

@@ -196,12 +196,13 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
             generic_images_folder: Optional[str] = None, generic_images_pattern: Optional[str] = None) -> int:
     """train.py:431-522: one JSON per frame under <output>/<seq>/<frame>.json; existing files are skipped."""
     from PIL import Image
-    if forward_dataset.lower() == "davis":
+    if forward_dataset.lower() == "davis":      # train.py:441-456: sequence paths are relative to the list file
+        pre = "/".join(davis_name.split("/")[:-1])
         with open(davis_name) as f:
-            seqs = [ln.strip() for ln in f if ln.strip()]
+            seqs = [ln.rstrip() for ln in f if ln.rstrip()]
         imgs = []
         for s in seqs:
-            imgs += sorted(glob.glob(s + "*"))
+            imgs += sorted(glob.glob(pre + "/" + s + "/*"))
     else:
         imgs = sorted(glob.glob(os.path.join(generic_images_folder, generic_images_pattern)))
     n = 0
@@ -226,6 +227,11 @@ def load_weights(path: str) -> Dict[str, object]:
     return torch.load(path, map_location="cpu")
 
 
+def infer_num_blocks(weights: Dict[str, object]):
+    """(3,4,23,3) for the shipped ResNet-101; read off the variable names so reduced nets load too."""
+    return tuple(len({k.split("/")[1] for k in weights if k.startswith(f"group{g}/block")}) for g in range(4))
+
+
 def main(argv: Optional[List[str]] = None) -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--load")
@@ -241,7 +247,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         raise SystemExit("only --forward (inference) is on the hot path; training is out of scope")
     if not a.agnostic:
         raise SystemExit("the shipped pipeline runs --agnostic (NUM_CLASS=2)")
-    pred = OfflinePredictor(ProposalNet(load_weights(a.load)))
+    w = load_weights(a.load)
+    pred = OfflinePredictor(ProposalNet(w, num_blocks=infer_num_blocks(w)))
     forward(pred, a.forward, a.forward_dataset, a.davis_name, a.generic_images_folder, a.generic_images_pattern)
     return 0
 

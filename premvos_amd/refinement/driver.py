@@ -108,9 +108,14 @@ def load_weights(path: str) -> Dict[str, object]:
     return torch.load(path, map_location="cpu")
 
 
+def infer_num_middle(weights: Dict[str, object]) -> int:
+    return len({k.split("/")[2] for k in weights if k.startswith("middle_flow/block1/unit_")})
+
+
 def refinement_net_init(config_path: str = "refinement_net/configs/live") -> RefinementEngine:
     cfg = Config(config_path)
-    return RefinementEngine(RefinementNet(load_weights(cfg.string("load"))))
+    w = load_weights(cfg.string("load"))
+    return RefinementEngine(RefinementNet(w, infer_num_middle(w)))
 
 
 def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_dir: str, output_dir: str) -> int:
@@ -136,7 +141,8 @@ def main(argv: Optional[List[str]] = None) -> int:
     argv = sys.argv[1:] if argv is None else argv
     assert len(argv) in (1, 2), "usage: driver.py <config> [update_config_string]"
     cfg = Config(argv[0], argv[1] if len(argv) > 1 else "")
-    engine = RefinementEngine(RefinementNet(load_weights(cfg.string("load"))))
+    w = load_weights(cfg.string("load"))
+    engine = RefinementEngine(RefinementNet(w, infer_num_middle(w)))
     forward_directory(engine, cfg.dir("image_input_dir"), cfg.dir("bb_input_dir"), cfg.dir("output_dir"))
     return 0
 

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Counterpart of simple_run.sh:21-58 for the stages on the hot path (A flow, B proposals x2, C combine, D refinement),
+with the script's own directory-exists resume (`if [ ! -d ... ]`).  Run from the PReMVOS root: same relative inputs
+(seq_to_run.txt, data/DAVIS/JPEGImages/480p/<seq>/) and outputs (output/intermediate/{flow,general_proposals,
+specific_proposals,combined_proposals,refined_proposals}/<seq>/...) that the unchanged ReID and MergeTrack stages read.
+
+Weights: torch pickles -- weights/PReMVOS_weights/optical_flow_net/pwc_net.pth.tar (the original file) and name->tensor
+dicts for the two TF nets, paths overridable on the command line.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from typing import List, Optional
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--root", default=".")
+    ap.add_argument("--seq_file", default="seq_to_run.txt")
+    ap.add_argument("--flow_weights", default="weights/PReMVOS_weights/optical_flow_net/pwc_net.pth.tar")
+    ap.add_argument("--general_weights", default="weights/PReMVOS_weights/proposal_net/general_weights/proposal_general_weights.pt")
+    ap.add_argument("--specific_weights", default="weights/PReMVOS_weights/proposal_net/specific_weights/proposal_specific_weights.pt")
+    ap.add_argument("--refinement_weights", default="weights/PReMVOS_weights/refinement_net/specific_weights/refinement_specific_weights.pt")
+    a = ap.parse_args(argv)
+    os.chdir(a.root)
+    inter = "output/intermediate"
+    done = []
+
+    flow_loc = f"{inter}/flow"
+    if not os.path.isdir(flow_loc):                                   # simple_run.sh:22-26
+        from premvos_amd.flow import driver as fd
+        fd.main([a.seq_file, a.flow_weights, flow_loc])
+        done.append("flow")
+    from premvos_amd.proposal import driver as pd
+    for loc, wfile in ((f"{inter}/general_proposals", a.general_weights),          # :28-42
+                       (f"{inter}/specific_proposals", a.specific_weights)):
+        if not os.path.isdir(loc):
+            pd.main(["--forward", loc, "--agnostic", "--second_head", "--forward_dataset", "DAVIS", "--load", wfile,
+                     "--davis_name", os.path.join(os.getcwd(), a.seq_file)])
+            done.append(os.path.basename(loc))
+    comb = f"{inter}/combined_proposals"
+    if not os.path.isdir(comb):                                       # :44-49
+        from premvos_amd.proposal.combine import combine
+        combine(inter + "/")
+        done.append("combined_proposals")
+    refined = f"{inter}/refined_proposals"
+    if not os.path.isdir(refined):                                    # :51-58
+        from premvos_amd.refinement import driver as rd
+        w = rd.load_weights(a.refinement_weights)
+        eng = rd.RefinementEngine(rd.RefinementNet(w, rd.infer_num_middle(w)))
+        rd.forward_directory(eng, "data/DAVIS/JPEGImages/480p/", comb + "/", refined + "/")
+        done.append("refined_proposals")
+    print("stages run:", done)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.exit(main())

@@ -1,0 +1,89 @@
+"""configs[0] of BASELINE.json: the 3-frame 'bear' clip through the stage drivers and file formats end to end
+(SURVEY 8d 'Config 1 (plumbing)'): .flo / proposal JSON / combined JSON / refined JSON exactly where and how the
+unchanged ReID + MergeTrack stages read them, with stage-level resume."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import proposal_oracle as PO  # noqa: E402
+from oracle import pwc_oracle as O  # noqa: E402
+from oracle import refinement_oracle as RO  # noqa: E402
+
+BLOCKS, MIDDLE = (1, 1, 2, 1), 1
+
+
+def _make_tree(root, h=120, w=200, t=3):
+    from PIL import Image
+    seq_dir = root / "data" / "DAVIS" / "JPEGImages" / "480p" / "bear"
+    seq_dir.mkdir(parents=True)
+    frames = []
+    for i in range(t):
+        pair = O.synth_frame_pair(h, w + (-w) % 8, seed=40, shift=(1.5 * i, -0.5 * i))
+        img = (pair[0, 3:, :, :w].permute(1, 2, 0) * 255).round().to(torch.uint8).numpy()
+        Image.fromarray(img).save(seq_dir / f"{i:05d}.jpg", quality=95)
+        frames.append(np.asarray(Image.open(seq_dir / f"{i:05d}.jpg").convert("RGB")))
+    (root / "seq_to_run.txt").write_text("data/DAVIS/JPEGImages/480p/bear/\n")
+    wd = root / "weights"
+    wd.mkdir()
+    torch.save({"state_dict": O.synth_state_dict(0)}, wd / "pwc.pth.tar")
+    torch.save(PO.synth_weights(0, BLOCKS), wd / "general.pt")
+    torch.save(PO.synth_weights(1, BLOCKS), wd / "specific.pt")
+    torch.save(RO.synth_weights(0, MIDDLE), wd / "refine.pt")
+    return frames
+
+
+def test_three_frame_clip_end_to_end(tmp_path):
+    from premvos_amd import rle, run_pipeline
+    from premvos_amd.flow.driver import readFlowFile
+    frames = _make_tree(tmp_path)
+    cwd = os.getcwd()
+    args = ["--root", str(tmp_path), "--flow_weights", "weights/pwc.pth.tar", "--general_weights", "weights/general.pt",
+            "--specific_weights", "weights/specific.pt", "--refinement_weights", "weights/refine.pt"]
+    try:
+        assert run_pipeline.main(args) == 0
+        inter = tmp_path / "output" / "intermediate"
+        # flow: named by the first frame of the pair, none for the last frame (script_pwc_multi.py:94-102)
+        flos = sorted(os.listdir(inter / "flow" / "bear"))
+        assert flos == ["00000.flo", "00001.flo"]
+        flo = readFlowFile(str(inter / "flow" / "bear" / "00000.flo"))
+        assert flo.shape == (120, 200, 2) and np.isfinite(flo).all()
+        # the .flo equals the oracle chain on the decoded JPEGs (script_pwc_multi.py:33-70)
+        from oracle import cv_resize_oracle as CR
+        x0, h_, w_ = CR.flow_preprocess(frames[0], frames[1])
+        with torch.no_grad():
+            ref = CR.flow_postprocess(O.pwc_forward(O.synth_state_dict(0), torch.from_numpy(x0))[0].numpy(), 120, 200, h_, w_)
+        assert np.abs(flo - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+        # proposals: one JSON per frame, bbox xywh 1 decimal, score 2 decimals; combined = general + specific
+        for t in range(3):
+            g = json.load(open(inter / "general_proposals" / "bear" / f"{t:05d}.json"))
+            s = json.load(open(inter / "specific_proposals" / "bear" / f"{t:05d}.json"))
+            c = json.load(open(inter / "combined_proposals" / "bear" / f"{t:05d}.json"))
+            r = json.load(open(inter / "refined_proposals" / "bear" / f"{t:05d}.json"))
+            assert c == g + s and len(r) == len(c) and len(g) <= 20 and len(s) <= 20
+            for p in c:
+                assert set(p) == {"bbox", "score"} and len(p["bbox"]) == 4
+                assert all(round(v, 1) == v for v in p["bbox"]) and round(p["score"], 2) == p["score"]
+            for p, q in zip(r, c):
+                assert p["bbox"] == q["bbox"] and p["score"] == q["score"]
+                assert p["segmentation"]["size"] == [120, 200] and isinstance(p["segmentation"]["counts"], str)
+                assert isinstance(p["conf_score"], str) and -1.0 <= float(p["conf_score"]) <= 1.0
+                m = rle.decode(p["segmentation"])
+                assert m.shape == (120, 200) and set(np.unique(m)) <= {0, 1}
+        # refined result of frame 0 equals the oracle forwarder on the same combined JSON
+        c0 = json.load(open(inter / "combined_proposals" / "bear" / "00000.json"))
+        r0 = json.load(open(inter / "refined_proposals" / "bear" / "00000.json"))
+        ref0 = RO.refine_proposals(RO.synth_weights(0, MIDDLE), frames[0], c0[:3], MIDDLE)
+        for a, b in zip(r0[:3], ref0):
+            assert abs(float(a["conf_score"]) - float(b["conf_score"])) < 2e-3
+            assert (rle.decode(a["segmentation"]) != RO.rle_decode(b["segmentation"])).mean() < 5e-3
+        # stage-level resume: nothing is recomputed when the directories exist (simple_run.sh:23,30,38,46,53)
+        before = {p: os.path.getmtime(p) for p in map(str, inter.rglob("*")) if os.path.isfile(p)}
+        assert run_pipeline.main(args) == 0
+        assert before == {p: os.path.getmtime(p) for p in before}
+    finally:
+        os.chdir(cwd)
