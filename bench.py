@@ -129,8 +129,15 @@ def roofline(pipe, batch):
         a = per_stage.setdefault(st, [0.0, 0.0])
         a[0] += f
         a[1] += t * m
+    traffic = None      # HBM bytes per launch from the PMC passes (profiles/r01_conv_hbm_traffic.json: method + corrections)
+    tf = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
+    if batch == 4 and os.path.exists(tf):
+        try:
+            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
     return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),
             "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
 
