@@ -106,9 +106,9 @@ def cpu_baseline():
 def roofline(pipe, batch):
     """Dominant kernel = conv_igemm_f32_kernel (every dense conv of the three nets).  HIP events around every one
     of its launches of one step, on the stream they are launched on; achieved = algorithmic FLOPs / time."""
-    reps = 3
+    reps = 5
     items = pipe.conv_steps()          # (stage, name, fn, flops_per_step)
-    tot = [0.0] * len(items)
+    samples = [[] for _ in items]
     for _ in range(reps):
         evs = []
         for _, _, fn, _ in items:
@@ -117,7 +117,8 @@ def roofline(pipe, batch):
             evs.append((a, b))
         torch.cuda.synchronize()
         for i, (a, b) in enumerate(evs):
-            tot[i] += a.elapsed_time(b) / reps
+            samples[i].append(a.elapsed_time(b))
+    tot = [sorted(x)[len(x) // 2] for x in samples]          # median per launch: robust to a throttling transient
     # refinement launches run once per frame of the batch: weight their time by the batch size
     mult = [batch if st == "refine" else 1 for st, _, _, _ in items]
     ms = sum(t * m for t, m in zip(tot, mult))

@@ -57,7 +57,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
   const int M = p.n * p.ho * p.wo;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (each XCD has a private 4 MB L2).  Give every
+  // XCD a contiguous chunk of the (m-tile major, n-tile minor) order, so the n-tiles that re-read one A (pixel) tile and
+  // the m-tiles that share halo rows run on the SAME L2.  Pure speed: any placement computes the same result.
+  int tile_m, tile_n;
+  {
+    const int n_tiles = gridDim.y, nwg = gridDim.x * gridDim.y;
+    const int id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    tile_m = v / n_tiles;
+    tile_n = v - tile_m * n_tiles;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-thread gather state -------------------------------------------------------------
   const int j4 = (tid % KU) * 4;  // this thread's float4 column inside the KB-deep stage
