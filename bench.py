@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PREMVOS_BENCH_BATCH", "4")),
                     help="frames per step per GPU")
+    ap.add_argument("--precision", default=os.environ.get("PREMVOS_BENCH_PRECISION", "fp32"),
+                    choices=["fp32", "bf16x3", "bf16", "mixed-bf16x3", "mixed-bf16"],
+                    help="MFMA arithmetic of the dense convs; mixed-*: PWC-Net fp32, proposal/refinement in the bf16 mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -166,8 +169,11 @@ def main():
     from premvos_amd.pipeline import FramePipeline
 
     B = a.batch
+    prec = a.precision
+    flow_prec = "fp32" if prec.startswith("mixed") else prec
+    net_prec = prec.split("-")[1] if prec.startswith("mixed") else prec
     pipe = FramePipeline(O.synth_state_dict(0), PO.synth_weights(0), PO.synth_weights(1), RO.synth_weights(0),
-                         batch=B, device=str(dev), boxes_per_frame=P_BOXES)
+                         batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec, flow_precision=flow_prec)
     fa, fb = synth_frames(B, rank)
     fa, fb = fa.to(dev), fb.to(dev)
     boxes = synth_boxes(B, rank).to(dev)
@@ -213,10 +219,14 @@ def main():
         "metric": "frames/sec (proposal+refine+flow) on 480p DAVIS frames",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (split-fp32 on the bf16 MFMA pipe, f32 accumulate)",
+                  "mixed-bf16x3": "flow f32; proposal+refinement bf16x3 (split-fp32, f32 accumulate)",
+                  "mixed-bf16": "flow f32; proposal+refinement bf16 (f32 accumulate)"}[prec],
+        "data": "synthetic",
         "config": {"workload": "configs[3] on one node: full per-frame pipe on synthetic DAVIS-shape 480x854 uint8 frames in "
                                "HBM: PWC-Net flow (512x896) + proposal_net x2 weight sets (749x1333, ResNet-101-C4, 100 RoIs) "
-                               f"+ refinement_net (Xception-65 DeepLabv3+, {P_BOXES} seeded boxes/frame @385x385); all fp32; "
+                               f"+ refinement_net (Xception-65 DeepLabv3+, {P_BOXES} seeded boxes/frame @385x385); conv arithmetic: {prec}; "
                                "results (flow, masks, conf, boxes) left in HBM",
                    "frames_per_step_per_gpu": B, "stages": ["flow", "proposal_general", "proposal_specific", "refinement"],
                    "gflop_per_frame": 2420,

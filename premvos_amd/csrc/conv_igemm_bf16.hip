@@ -22,16 +22,21 @@ int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipS
 
 namespace {
 
-constexpr int BK = 32;            // k depth per LDS stage (floats / bf16 elements)
-constexpr int RSB = 80;           // LDS row stride in BYTES: 32 bf16 (64 B) + 16 B pad
+constexpr int BK = 32;            // k granularity of the packed bf16 weights (k_pad % 32 == 0)
 
-template <int BM, int BN, int WM, int WN, int NPASS, bool PIXSHUF, bool SPLITK>
+// KB = k depth of one LDS stage (16 or 32).  LDS rows are KB bf16 + 16 B pad (48 B / 80 B = 12 / 20 dwords, both 4 x odd:
+// 16 consecutive rows hit 16 different 16-byte bank slots).  The 16-deep stage halves the LDS per workgroup so twice
+// as many workgroups are resident per CU -- this kernel is latency-bound (SQ_WAIT_ANY 0.6), not MFMA-bound.
+template <int BM, int BN, int WM, int WN, int NPASS, bool PIXSHUF, bool SPLITK, int KB>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const premvos_conv_desc p, const int kt_per) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
   constexpr int PARTS = NPASS == 3 ? 2 : 1;                  // hi (+ lo)
-  constexpr int ROWS_PER_PASS = NT / 8;                      // 8 float4 units per 32-deep row
+  constexpr int RSB = KB * 2 + 16;                           // LDS row stride in bytes
+  constexpr int KU = KB / 4;                                 // float4 units per row (A)
+  constexpr int BC = KB / 8;                                 // 16-byte bf16 chunks per row and part (B)
+  constexpr int ROWS_PER_PASS = NT / KU;
   constexpr int A_PER_T = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
   constexpr int B_PER_T = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
   constexpr int PART_BYTES_A = BM * RSB, PART_BYTES_B = BN * RSB;
@@ -45,12 +50,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
   const int M = p.n * p.ho * p.wo;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-  const int j = tid & 7;           // float4 unit inside the 32-deep stage (A); 16-byte bf16 chunk (B: j&3, part j>>2)
+  const int j = tid % KU;          // float4 unit inside the stage (A); 16-byte bf16 chunk j % BC of part j / BC (B)
   const float* rowbase[A_PER_T];
   int iy0[A_PER_T], ix0[A_PER_T];
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
-    const int row = (tid >> 3) + i * ROWS_PER_PASS;
+    const int row = (tid / KU) + i * ROWS_PER_PASS;
     const int m = m0 + row;
     const bool ok = (row < BM) && (m < M);
     const int mm = ok ? m : 0;
@@ -61,27 +66,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
     iy0[i] = ok ? oy * p.sh - p.pt : -(1 << 28);
     ix0[i] = ox * p.sw - p.pl;
   }
-  const int KT_all = p.k_pad / BK;
+  const int KT_all = p.k_pad / KB;
   const int kt_begin = SPLITK ? blockIdx.z * kt_per : 0;
   const int kt_end = SPLITK ? (kt_begin + kt_per < KT_all ? kt_begin + kt_per : KT_all) : KT_all;
   int kh, kw, c;
   {
-    const int k0 = kt_begin * BK + j * 4;
+    const int k0 = kt_begin * KB + j * 4;
     const int tap = k0 / p.cin_pad;
     c = k0 - tap * p.cin_pad;
     kh = tap / p.kw;
     kw = tap - kh * p.kw;
   }
   // weights: hi array at p.wgt, lo array at p.wgt_lo, both [cout_pad][k_pad] bf16
-  const bool b_active = (j >> 2) < PARTS;
-  const unsigned short* wbase = reinterpret_cast<const unsigned short*>((j >> 2) ? p.wgt_lo : p.wgt);
+  const bool b_active = (j / BC) < PARTS;
+  const unsigned short* wbase = reinterpret_cast<const unsigned short*>((j / BC) ? p.wgt_lo : p.wgt);
   const unsigned short* wrow[B_PER_T];
   bool wok[B_PER_T];
 #pragma unroll
   for (int i = 0; i < B_PER_T; ++i) {
-    const int row = (tid >> 3) + i * ROWS_PER_PASS;
+    const int row = (tid / KU) + i * ROWS_PER_PASS;
     wok[i] = b_active && (row < BN) && (n0 + row < p.cout_pad);
-    wrow[i] = wbase + (long)(wok[i] ? n0 + row : 0) * p.k_pad + (j & 3) * 8;
+    wrow[i] = wbase + (long)(wok[i] ? n0 + row : 0) * p.k_pad + (j % BC) * 8;
   }
 
   float4 ra[A_PER_T];
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i)
-      rb[i] = wok[i] ? *reinterpret_cast<const uint4*>(wrow[i] + (long)kt * BK) : make_uint4(0, 0, 0, 0);
-    c += BK;
+      rb[i] = wok[i] ? *reinterpret_cast<const uint4*>(wrow[i] + (long)kt * KB) : make_uint4(0, 0, 0, 0);
+    c += KB;
     while (c >= p.cin_pad) {
       c -= p.cin_pad;
       if (++kw == p.kw) { kw = 0; ++kh; }
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
     char* base = lds + buf * BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
-      const int row = (tid >> 3) + i * ROWS_PER_PASS;
+      const int row = (tid / KU) + i * ROWS_PER_PASS;
       if (BM % ROWS_PER_PASS == 0 || row < BM) {
         const float4 v = ra[i];
         const bf16x4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -121,11 +126,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
         }
       }
     }
-    char* bb = base + PARTS * PART_BYTES_A + (j >> 2) * PART_BYTES_B;
+    char* bb = base + PARTS * PART_BYTES_A + (j / BC) * PART_BYTES_B;
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
-      const int row = (tid >> 3) + i * ROWS_PER_PASS;
-      if (b_active && (BN % ROWS_PER_PASS == 0 || row < BN)) *reinterpret_cast<uint4*>(bb + row * RSB + (j & 3) * 16) = rb[i];
+      const int row = (tid / KU) + i * ROWS_PER_PASS;
+      if (b_active && (BN % ROWS_PER_PASS == 0 || row < BN)) *reinterpret_cast<uint4*>(bb + row * RSB + (j % BC) * 16) = rb[i];
     }
   };
 
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
     const char* a_hi = base + wm0 * RSB + frag_off;
     const char* b_hi = base + PARTS * PART_BYTES_A + wn0 * RSB + frag_off;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {          // two 16-deep MFMA k blocks per stage
+    for (int s = 0; s < KB / 16; ++s) {    // 16-deep MFMA k blocks of the stage
       bf16x8 ah[MT], al[MT], bh[NTL], bl[NTL];
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
@@ -239,14 +244,16 @@ inline void pick_tile(const premvos_conv_desc& d, int* bm, int* bn) {
   *bm = blocks128 >= 512 ? 128 : 64;
 }
 
+inline int pick_kb(const premvos_conv_desc& d) { return d.stage_k == 32 ? 32 : 16; }
+
 inline int pick_splits(const premvos_conv_desc& d, int bm, int bn) {
   if (d.split_k > 0) return d.split_k;
   if (d.split_k < 0) return 1;
   const long tiles = (long)premvos::cdiv(d.n * d.ho * d.wo, bm) * premvos::cdiv(d.cout, bn);
-  const int KT = d.k_pad / BK;
-  if (tiles >= 384 || KT < 16) return 1;
+  const int KT = d.k_pad / 32;
+  if (tiles >= 384 || KT < 8) return 1;
   long s = (768 + tiles - 1) / tiles;
-  if (s > KT / 8) s = KT / 8;
+  if (s > KT / 4) s = KT / 4;
   if (s > 32) s = 32;
   return s < 2 ? 1 : (int)s;
 }
@@ -256,21 +263,21 @@ inline void allow_lds(K kernel, int bytes) {   // > 64 KB of LDS per workgroup n
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-template <int BM, int BN, int WM, int WN, int NPASS>
+template <int BM, int BN, int WM, int WN, int NPASS, int KB>
 int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   const int M = d.n * d.ho * d.wo;
   dim3 grid(premvos::cdiv(M, BM), premvos::cdiv(d.cout, BN));
   dim3 block(64 * WM * WN);
-  constexpr int LDS_BYTES = 2 * (NPASS == 3 ? 2 : 1) * (BM + BN) * RSB;
+  constexpr int LDS_BYTES = 2 * (NPASS == 3 ? 2 : 1) * (BM + BN) * (KB * 2 + 16);
   static bool attr_done = false;
   if (!attr_done) {
-    allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, true>, LDS_BYTES);
-    allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, true, false>, LDS_BYTES);
-    allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, false>, LDS_BYTES);
+    allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, true, KB>, LDS_BYTES);
+    allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, true, false, KB>, LDS_BYTES);
+    allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, false, KB>, LDS_BYTES);
     attr_done = true;
   }
   int splits = pick_splits(d, BM, BN);
-  const int KT = d.k_pad / BK;
+  const int KT = d.k_pad / KB;
   if (splits > 1) {
     const int kt_per = premvos::cdiv(KT, splits);
     splits = premvos::cdiv(KT, kt_per);
@@ -278,7 +285,7 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     const long need = (long)splits * M * ncols * sizeof(float);
     if (splits > 1 && d.workspace != nullptr && (long)d.workspace_bytes >= need) {
       grid.z = splits;
-      hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, true>), grid, block, LDS_BYTES, s, d, kt_per);
+      hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per);
       int rc = premvos::check_launch("conv_igemm_bf16(split-k)");
       if (rc) return rc;
       return premvos::launch_splitk_reduce(d, splits, ncols, s);
@@ -286,25 +293,30 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     if (d.split_k > 0) return premvos::fail(PREMVOS_EINVAL, "conv2d: split_k=%d needs %ld workspace bytes", d.split_k, need);
   }
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, true, false>), grid, block, LDS_BYTES, s, d, 0);
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, true, false, KB>), grid, block, LDS_BYTES, s, d, 0);
   else
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, false>), grid, block, LDS_BYTES, s, d, 0);
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, false, KB>), grid, block, LDS_BYTES, s, d, 0);
   return premvos::check_launch("conv_igemm_bf16");
+}
+
+template <int NPASS, int KB>
+int dispatch_kb(const premvos_conv_desc& d, hipStream_t s) {
+  int bm, bn;
+  pick_tile(d, &bm, &bn);
+  switch ((bm << 16) | bn) {
+    case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2, NPASS, KB>(d, s);
+    case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2, NPASS, KB>(d, s);
+    case (128 << 16) | 32: return launch_cfg<128, 32, 4, 1, NPASS, KB>(d, s);
+    case (64 << 16) | 128: return launch_cfg<64, 128, 2, 2, NPASS, KB>(d, s);
+    case (64 << 16) | 64: return launch_cfg<64, 64, 2, 2, NPASS, KB>(d, s);
+    case (64 << 16) | 32: return launch_cfg<64, 32, 2, 1, NPASS, KB>(d, s);
+    default: return premvos::fail(PREMVOS_EINVAL, "conv2d(bf16): no tile config %dx%d", bm, bn);
+  }
 }
 
 template <int NPASS>
 int dispatch(const premvos_conv_desc& d, hipStream_t s) {
-  int bm, bn;
-  pick_tile(d, &bm, &bn);
-  switch ((bm << 16) | bn) {
-    case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2, NPASS>(d, s);
-    case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2, NPASS>(d, s);
-    case (128 << 16) | 32: return launch_cfg<128, 32, 4, 1, NPASS>(d, s);
-    case (64 << 16) | 128: return launch_cfg<64, 128, 2, 2, NPASS>(d, s);
-    case (64 << 16) | 64: return launch_cfg<64, 64, 2, 2, NPASS>(d, s);
-    case (64 << 16) | 32: return launch_cfg<64, 32, 2, 1, NPASS>(d, s);
-    default: return premvos::fail(PREMVOS_EINVAL, "conv2d(bf16): no tile config %dx%d", bm, bn);
-  }
+  return pick_kb(d) == 32 ? dispatch_kb<NPASS, 32>(d, s) : dispatch_kb<NPASS, 16>(d, s);
 }
 
 }  // namespace
@@ -325,7 +337,7 @@ long conv2d_bf16_workspace_bytes(const premvos_conv_desc& d) {
   pick_tile(d, &bm, &bn);
   int splits = pick_splits(d, bm, bn);
   if (splits <= 1) return 0;
-  const int KT = d.k_pad / BK;
+  const int KT = d.k_pad / pick_kb(d);
   const int kt_per = cdiv(KT, splits);
   splits = cdiv(KT, kt_per);
   if (splits <= 1) return 0;

@@ -23,10 +23,10 @@ class FramePipeline:
                  prop_specific: Dict[str, object], refine_w: Dict[str, object], batch: int = 1,
                  device: str = "cuda", boxes_per_frame: int = RESULTS_PER_IM,
                  num_blocks: Sequence[int] = RESNET_NUM_BLOCK, num_middle: int = 16, concurrent: bool = True,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, flow_precision: Optional[str] = None):
         self.batch, self.device, self.P = batch, device, boxes_per_frame
         self.precision = precision
-        self.flow = FlowStage(flow_sd, batch=batch, device=device, precision=precision)
+        self.flow = FlowStage(flow_sd, batch=batch, device=device, precision=flow_precision or precision)
         self.prop_g = ProposalStage(prop_general, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True,
                                     precision=precision)
         self.prop_s = ProposalStage(prop_specific, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True,
