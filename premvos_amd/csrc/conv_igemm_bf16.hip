@@ -207,13 +207,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
     const float bv = (p.bias != nullptr && colok) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
+      // residual rows of this 32x32 tile are fetched as 16 independent loads BEFORE they are consumed: a load-use
+      // chain per element made the short-K bottleneck layers (ResNet conv3 + shortcut) latency-bound at ~1 TB/s
+      float rv[16];
+      if (p.res != nullptr) {     // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          rv[r] = (colok && m < M) ? p.res[(long)m * p.res_ps + col] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int m = m0 + row;
         if (!colok || m >= M) continue;
-        float v = acc[mi][ni][r] + bv;
-        if (p.res != nullptr) v += p.res[(long)m * p.res_ps + col];
+        float v = acc[mi][ni][r] + bv + rv[r];
         if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
         else if (p.act == PREMVOS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
         else if (p.act == PREMVOS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
@@ -228,6 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
           p.out[(long)m * p.out_ps + col] = v;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the next tile's 16 residual loads from being hoisted (VGPR budget)
     }
   }
 }
