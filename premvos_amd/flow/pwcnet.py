@@ -148,7 +148,7 @@ class _Plan:
         steps.append(("nhwc_to_nchw", lambda s=flow2, d=self.flow_out: ops.nhwc_to_nchw(s, d)))
         self.steps = steps
         self.buffers = keep
-        self.ws = ops.assign_workspace(self.descs, dev)      # split-K scratch shared by the whole launch list
+        self.ws = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)      # split-K scratch shared by the whole launch list
         self.feats, self.xbufs = feats, xbufs
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 

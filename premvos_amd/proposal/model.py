@@ -195,7 +195,7 @@ class _Plan:
             self.final_masks = alloc(b * M, 14, 14, NUM_CLASS - 1)
             conv(up, "maskrcnn/conv", self.final_masks, act=ACT_SIGMOID)
         self.steps, self.buffers = steps, keep
-        self.ws_splitk = ops.assign_workspace(self.descs, dev)
+        self.ws_splitk = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def run(self, steps=None):

@@ -221,7 +221,7 @@ class _Plan:
                 self.conf.data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
         steps.append(("refine_output", out_layer))
         self.steps, self.buffers = steps, keep
-        self.ws_splitk = ops.assign_workspace(self.descs, dev)
+        self.ws_splitk = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def run(self, steps=None):
