@@ -232,6 +232,10 @@ def autotune(descs, device="cuda", reps: int = 4):
         return
     lib = _lib.load()
     stream = _lib.current_stream()
+    cache_file = os.environ.get("PREMVOS_TUNE_CACHE")        # optional: reuse a previous process's choices
+    if cache_file and not _TUNE_CACHE and os.path.exists(cache_file):
+        import json
+        _TUNE_CACHE.update({tuple(k): tuple(v) for k, v in json.load(open(cache_file))})
     todo = [d for d in descs if _sig(d) not in _TUNE_CACHE]
     if todo:
         need = 0
@@ -261,6 +265,9 @@ def autotune(descs, device="cuda", reps: int = 4):
                     best, best_t = (th, st, sk), t
             _TUNE_CACHE[sig] = best
             d.workspace, d.workspace_bytes = None, 0
+        if cache_file:
+            import json
+            json.dump([[list(k), list(v)] for k, v in _TUNE_CACHE.items()], open(cache_file, "w"))
     for d in descs:
         d.tile_hint, d.stage_k, d.split_k = _TUNE_CACHE[_sig(d)]
 
