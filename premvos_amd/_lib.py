@@ -100,6 +100,8 @@ def load():
         fn.restype = C.c_int
     lib.premvos_conv2d_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     lib.premvos_conv2d_workspace_bytes.restype = C.c_int64
+    lib.premvos_crc32c_host.argtypes = [_vp, C.c_int64]
+    lib.premvos_crc32c_host.restype = C.c_uint32
     lib.premvos_refine_output_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
     lib.premvos_refine_output_workspace_bytes.restype = C.c_int64
     _LIB = lib

@@ -222,9 +222,10 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
 
 
 def load_weights(path: str) -> Dict[str, object]:
-    """Weight container: a torch pickle of the name->tensor dict documented in ProposalNet.  (TF tensor-bundle
-    import is a 'next' row, SURVEY 8f-3: TensorFlow is absent from the build image.)"""
-    return torch.load(path, map_location="cpu")
+    """``--load`` accepts what simple_run.sh:31-33 passes -- a TF checkpoint prefix (read without TensorFlow by
+    premvos_amd.weights) -- or a torch pickle of the name->tensor dict documented in ProposalNet."""
+    from ..weights import load_any
+    return load_any(path, "proposal")
 
 
 def infer_num_blocks(weights: Dict[str, object]):

@@ -105,7 +105,9 @@ def do_refinement(proposals: List[dict], image_fn: str, refinement_net: Refineme
 
 
 def load_weights(path: str) -> Dict[str, object]:
-    return torch.load(path, map_location="cpu")
+    """config key "load" (configs/run:9): a TF checkpoint prefix (read without TensorFlow) or a torch pickle."""
+    from ..weights import load_any
+    return load_any(path, "refinement")
 
 
 def infer_num_middle(weights: Dict[str, object]) -> int:

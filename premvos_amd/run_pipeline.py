@@ -4,8 +4,9 @@ with the script's own directory-exists resume (`if [ ! -d ... ]`).  Run from the
 (seq_to_run.txt, data/DAVIS/JPEGImages/480p/<seq>/) and outputs (output/intermediate/{flow,general_proposals,
 specific_proposals,combined_proposals,refined_proposals}/<seq>/...) that the unchanged ReID and MergeTrack stages read.
 
-Weights: torch pickles -- weights/PReMVOS_weights/optical_flow_net/pwc_net.pth.tar (the original file) and name->tensor
-dicts for the two TF nets, paths overridable on the command line.
+Weights: the reference's own files at the reference's own paths -- optical_flow_net/pwc_net.pth.tar (torch pickle) and the
+TF checkpoint prefixes of the two TF nets (simple_run.sh:31-32,39-40; refinement_net/configs/run:9), read without
+TensorFlow by premvos_amd/weights.py; torch pickles of name->tensor dicts are accepted too.
 """
 from __future__ import annotations
 
@@ -20,9 +21,9 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--root", default=".")
     ap.add_argument("--seq_file", default="seq_to_run.txt")
     ap.add_argument("--flow_weights", default="weights/PReMVOS_weights/optical_flow_net/pwc_net.pth.tar")
-    ap.add_argument("--general_weights", default="weights/PReMVOS_weights/proposal_net/general_weights/proposal_general_weights.pt")
-    ap.add_argument("--specific_weights", default="weights/PReMVOS_weights/proposal_net/specific_weights/proposal_specific_weights.pt")
-    ap.add_argument("--refinement_weights", default="weights/PReMVOS_weights/refinement_net/specific_weights/refinement_specific_weights.pt")
+    ap.add_argument("--general_weights", default="weights/PReMVOS_weights/proposal_net/general_weights/proposal_general_weights")
+    ap.add_argument("--specific_weights", default="weights/PReMVOS_weights/proposal_net/specific_weights/proposal_specific_weights")
+    ap.add_argument("--refinement_weights", default="weights/PReMVOS_weights/refinement_net/specific_weights/refinement_specific_weights")
     a = ap.parse_args(argv)
     os.chdir(a.root)
     inter = "output/intermediate"

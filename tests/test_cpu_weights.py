@@ -1,0 +1,85 @@
+"""TF tensor-bundle reader/writer + variable-name maps (no TensorFlow, no GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import proposal_oracle as PO
+from oracle import refinement_oracle as RO
+from premvos_amd import weights as W
+
+
+def test_crc32c_known_answers():
+    assert W.crc32c(b"") == 0 and W.crc32c(b"123456789") == 0xE3069283          # CRC-32C check value
+    assert W.crc32c(bytes(32)) == 0x8A9136AA                                      # RFC 3720 B.4: 32 zero bytes
+
+
+def test_snappy_decompress():
+    # literal "abcd", copy(offset 4, len 8) (overlapping run), literal "Z"
+    stream = bytes([13]) + bytes([(4 - 1) << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4]) + bytes([0 << 2]) + b"Z"
+    assert W.snappy_decompress(stream) == b"abcdabcdabcdZ"
+    with pytest.raises(ValueError):
+        W.snappy_decompress(bytes([99]) + bytes([0]) + b"a")
+
+
+def test_bundle_roundtrip_multi_block(tmp_path):
+    rng = np.random.default_rng(0)
+    v = {f"scope_{i:03d}/layer/W": rng.standard_normal((3, 3, 4, 5)).astype(np.float32) for i in range(150)}
+    v["global_step"] = np.array(1234, np.int64)
+    v["a/very/long/name/" + "x" * 300] = np.arange(7, dtype=np.int32)
+    v["empty"] = np.zeros((0, 4), np.float32)
+    prefix = str(tmp_path / "ckpt")
+    W.save_tf_checkpoint(prefix, v, block_size=512)
+    raw = open(prefix + ".index", "rb").read()
+    assert raw[-8:] == (0xDB4775248B80FB57).to_bytes(8, "little") and len(raw) > 4096       # several data blocks
+    back = W.load_tf_checkpoint(prefix, verify=True)
+    assert set(back) == set(v)
+    for k in v:
+        assert back[k].dtype == v[k].dtype and back[k].shape == v[k].shape and np.array_equal(back[k], v[k])
+    # corruption is detected
+    bad = bytearray(raw)
+    bad[10] ^= 0xFF
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        W.read_table(prefix + ".index")
+    open(prefix + ".index", "wb").write(raw[:-1])
+    with pytest.raises(ValueError):
+        W.read_table(prefix + ".index")
+
+
+def _same(a, b):
+    assert set(a) == set(b)
+    for k in a:
+        if isinstance(a[k], dict):
+            for f in a[k]:
+                assert torch.equal(a[k][f], b[k][f]), (k, f)
+        else:
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+
+
+def test_proposal_name_and_layout_map(tmp_path):
+    w = PO.synth_weights(0, (1, 1, 2, 1))
+    tfv = W.proposal_weights_to_tf(w)
+    # tensorpack names / TF layouts
+    assert tfv["conv0/W"].shape == (7, 7, 3, 64) and tfv["group2/block1/conv2/W"].shape == (3, 3, 256, 256)
+    assert tfv["rpn/class/W"].shape == (1, 1, 1024, 15) and tfv["fastrcnn/class/W"].shape == (2048, 2)
+    assert tfv["maskrcnn/deconv/W"].shape == (2, 2, 256, 2048)
+    assert {"conv0/bn/gamma", "conv0/bn/beta", "conv0/bn/mean/EMA", "conv0/bn/variance/EMA"} <= set(tfv)
+    prefix = str(tmp_path / "proposal_general_weights")
+    W.save_tf_checkpoint(prefix, tfv)
+    _same(W.load_any(prefix, "proposal"), w)
+
+
+def test_refinement_name_and_layout_map(tmp_path):
+    w = RO.synth_weights(0, 1)
+    tfv = W.refinement_weights_to_tf(w)
+    assert tfv["xception_65/entry_flow/conv1_1/weights"].shape == (3, 3, 4, 32)          # 4-channel stem (Saver.py:103-106)
+    k = "xception_65/middle_flow/block1/unit_1/xception_module/separable_conv2_depthwise/depthwise_weights"
+    assert tfv[k].shape == (3, 3, 728, 1)
+    assert "xception_65/entry_flow/conv1_1/BatchNorm/moving_variance" in tfv
+    assert tfv["logits/features/weights"].shape == (1, 1, 256, 2) and tfv["logits/features/biases"].shape == (2,)
+    assert tfv["decoder/decoder_conv0_depthwise/depthwise_weights"].shape == (3, 3, 304, 1)
+    prefix = str(tmp_path / "refinement_specific_weights")
+    W.save_tf_checkpoint(prefix, tfv)
+    _same(W.load_any(prefix, "refinement"), w)
+    torch.save(w, str(tmp_path / "w.pt"))
+    _same(W.load_any(str(tmp_path / "w.pt"), "refinement"), w)

@@ -31,9 +31,11 @@ def _make_tree(root, h=120, w=200, t=3):
     wd = root / "weights"
     wd.mkdir()
     torch.save({"state_dict": O.synth_state_dict(0)}, wd / "pwc.pth.tar")
-    torch.save(PO.synth_weights(0, BLOCKS), wd / "general.pt")
+    from premvos_amd import weights as W
+    # general + refinement as TF tensor-bundle checkpoints (what simple_run.sh passes), specific as a torch pickle
+    W.save_tf_checkpoint(str(wd / "proposal_general_weights"), W.proposal_weights_to_tf(PO.synth_weights(0, BLOCKS)))
     torch.save(PO.synth_weights(1, BLOCKS), wd / "specific.pt")
-    torch.save(RO.synth_weights(0, MIDDLE), wd / "refine.pt")
+    W.save_tf_checkpoint(str(wd / "refinement_specific_weights"), W.refinement_weights_to_tf(RO.synth_weights(0, MIDDLE)))
     return frames
 
 
@@ -42,8 +44,9 @@ def test_three_frame_clip_end_to_end(tmp_path):
     from premvos_amd.flow.driver import readFlowFile
     frames = _make_tree(tmp_path)
     cwd = os.getcwd()
-    args = ["--root", str(tmp_path), "--flow_weights", "weights/pwc.pth.tar", "--general_weights", "weights/general.pt",
-            "--specific_weights", "weights/specific.pt", "--refinement_weights", "weights/refine.pt"]
+    args = ["--root", str(tmp_path), "--flow_weights", "weights/pwc.pth.tar", "--general_weights",
+            "weights/proposal_general_weights", "--specific_weights", "weights/specific.pt", "--refinement_weights",
+            "weights/refinement_specific_weights"]
     try:
         assert run_pipeline.main(args) == 0
         inter = tmp_path / "output" / "intermediate"
