@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import glob
 import json
+from collections import OrderedDict
 import os
 import sys
 from typing import Dict, List, Optional
@@ -26,36 +27,69 @@ from .model import RefinementNet
 
 
 class Config:
-    """core/Config.py: JSON file, lines starting with '#' stripped; typed getters with defaults."""
+    """core/Config.py:5-91 -- JSON file whose '#' comment lines are blanked; typed getters that do NOT coerce: a value of
+    the wrong JSON type raises TypeError, a missing key without a default fails its assertion (same as the reference).
+    ``update_config_string`` (main.py's second argument) is a JSON object merged on top."""
 
     def __init__(self, filename: str, update_config_string: str = ""):
-        lines = [ln for ln in open(filename).readlines() if not ln.strip().startswith("#")]
-        self._entries = json.loads("\n".join(lines))
+        lines = [ln if not ln.strip().startswith("#") else "\n" for ln in open(filename).readlines()]
+        self._entries = json.loads("".join(lines), object_pairs_hook=OrderedDict)
         if update_config_string:
-            self._entries.update(json.loads(update_config_string))
+            self._entries.update(json.loads(update_config_string, object_pairs_hook=OrderedDict))
 
-    def has(self, key): return key in self._entries
+    def has(self, key):
+        return key in self._entries
 
-    def _get(self, key, typ, default):
+    def _value(self, key, dtype, default):
+        if default is not None:
+            assert isinstance(default, dtype)
         if key in self._entries:
-            return typ(self._entries[key])
-        if default is None:
-            raise KeyError(f"missing config key {key}")
+            val = self._entries[key]
+            if isinstance(val, dtype):
+                return val
+            raise TypeError()
+        assert default is not None
         return default
 
-    def int(self, key, default=None): return self._get(key, int, default)
-    def float(self, key, default=None): return self._get(key, float, default)
-    def bool(self, key, default=None): return self._get(key, bool, default)
-    def string(self, key, default=None): return self._get(key, str, default)
+    def _list_value(self, key, dtype, default):
+        if default is not None:
+            assert isinstance(default, list)
+            for x in default:
+                assert isinstance(x, dtype)
+        if key in self._entries:
+            val = self._entries[key]
+            assert isinstance(val, list)
+            for x in val:
+                assert isinstance(x, dtype)
+            return val
+        assert default is not None
+        return default
+
+    def bool(self, key, default=None): return self._value(key, bool, default)
+    def string(self, key, default=None): return self._value(key, str, default)
+    def int(self, key, default=None): return self._value(key, int, default)
+    def float(self, key, default=None): return self._value(key, float, default)
+    def dict(self, key, default=None): return self._value(key, dict, default)
+    def int_list(self, key, default=None): return self._list_value(key, int, default)
+    def float_list(self, key, default=None): return self._list_value(key, float, default)
+    def string_list(self, key, default=None): return self._list_value(key, str, default)
+
+    def int_key_dict(self, key, default=None):
+        if default is not None:
+            assert isinstance(default, dict) and all(isinstance(k, int) for k in default)
+        dict_str = self.string(key, "")
+        if dict_str == "":
+            assert default is not None
+            res = default
+        else:
+            import ast
+            res = ast.literal_eval(dict_str)
+        assert isinstance(res, dict) and all(isinstance(k, int) for k in res)
+        return res
+
     def dir(self, key, default=None):
         p = self.string(key, default)
-        return p if p.endswith("/") else p + "/"
-
-    def int_list(self, key, default=None):
-        v = self._entries.get(key, default)
-        if v is None:
-            raise KeyError(key)
-        return [int(x) for x in v]
+        return p if p[-1] == "/" else p + "/"
 
 
 def _boxes_from_proposals(proposals: List[dict]) -> np.ndarray:

@@ -1,0 +1,79 @@
+"""Host-side pieces checked against vectors produced by importing / running the reference's own pure-python modules
+(tools/make_golden_host.py -> tests/golden/host_refs.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_refs.json")))
+
+
+def test_anchor_table_matches_reference_generate_anchors():
+    from oracle import proposal_oracle as PO
+    from premvos_amd.proposal import model as PM
+    a = G["anchors"]
+    ref = np.array(a["out"])
+    got = PO.generate_anchors(a["stride"], a["ratios"], np.array(a["sizes"], np.float64) / a["stride"])
+    assert got.shape == ref.shape == (15, 4) and np.array_equal(got, ref)
+    assert np.array_equal(PO.generate_anchors(), np.array(a["default"]))
+    # oracle and product: the same table + data.py:73's "+1" on x1,y1, in float32
+    want = ref.astype(np.float32)
+    want[:, 2:] += 1
+    assert np.array_equal(PO.cell_anchors(), want)
+    assert np.array_equal(PM.cell_anchors(), want)
+
+
+def test_combine_matches_reference_script(tmp_path):
+    from premvos_amd.proposal.combine import combine
+    c = G["combine"]
+    root = tmp_path / "output" / "intermediate"
+    for rel, v in c["inputs"].items():
+        fn = root / rel
+        fn.parent.mkdir(parents=True, exist_ok=True)
+        fn.write_text("{not json" if rel == c["corrupt"] else json.dumps(v))
+    (root / c["corrupt"]).parent.mkdir(parents=True, exist_ok=True)
+    (root / c["corrupt"]).write_text("{not json")
+    combine(str(root) + "/")
+    got = {}
+    base = root / "combined_proposals"
+    for d, _, fs in os.walk(base):
+        for fn in fs:
+            got[os.path.relpath(os.path.join(d, fn), base)] = json.load(open(os.path.join(d, fn)))
+    assert got == c["combined"]
+    # inputs untouched
+    for rel, v in c["inputs"].items():
+        if rel != c["corrupt"]:
+            assert json.load(open(root / rel)) == v
+
+
+def test_refinement_normalisation_constants():
+    from oracle import refinement_oracle as RO
+    n = G["normalize"]
+    assert np.array_equal(RO.IMAGENET_RGB_MEAN, np.array(n["mean"], np.float32))
+    assert np.array_equal(RO.IMAGENET_RGB_STD, np.array(n["std"], np.float32))
+    img = np.array(n["img"], np.float32)
+    assert np.array_equal((img - RO.IMAGENET_RGB_MEAN) / RO.IMAGENET_RGB_STD, np.array(n["out"], np.float32))
+
+
+def test_config_getters_and_errors_match_reference(tmp_path):
+    from premvos_amd.refinement.driver import Config
+    fn = tmp_path / "run"
+    fn.write_text(G["config"]["text"])
+    c = Config(str(fn))
+    for k, v in G["config"]["has"].items():
+        assert c.has(k) == v
+    for call in G["config"]["calls"]:
+        f = getattr(c, call["method"])
+        if "raises" in call:
+            with pytest.raises({"TypeError": TypeError, "AssertionError": AssertionError}[call["raises"]]):
+                f(call["key"], call["default"])
+        else:
+            v = f(call["key"], call["default"])
+            if call["method"] == "int_key_dict":
+                v = {str(k): x for k, x in v.items()}
+            assert v == call["value"], call
+    # '#' comment lines are dropped, the override string of main.py is merged on top
+    fn.write_text('# comment\n{"a": 1,\n  # another\n "b": "x"}\n')
+    c = Config(str(fn), '{"b": "y"}')
+    assert c.int("a") == 1 and c.string("b") == "y"
