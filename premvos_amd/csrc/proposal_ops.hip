@@ -377,6 +377,35 @@ __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ in, 
   }
 }
 
+// Large-hw variant (ASPP image pooling: hw = 625, n = boxes): one block = 32 channel quads x 8 pixel slices, partial sums
+// combined through LDS in slice order (deterministic).
+__global__ __launch_bounds__(256) void gap_sliced_kernel(const float* __restrict__ in, int in_ps, int hw, int c4,
+                                                         float* __restrict__ out, int out_ps) {
+  __shared__ float4 part[8][32];
+  const int lane = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int cg = blockIdx.x * 32 + lane;
+  const long b = blockIdx.y;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cg < c4) {
+    const float* base = in + b * hw * (long)in_ps + cg * 4;
+    for (int i = slice; i < hw; i += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (long)i * in_ps);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && cg < c4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float4 v = part[k][lane];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = (float)hw;
+    *reinterpret_cast<float4*>(out + b * out_ps + cg * 4) = make_float4(s.x / inv, s.y / inv, s.z / inv, s.w / inv);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fast R-CNN inference tail for the class-agnostic net (train.py:275-295, model.py:438-491):
 // softmax over {bg,fg}, decode deltas/[10,10,5,5] on the proposals, clip, keep p > thresh, greedy NMS
@@ -531,8 +560,13 @@ extern "C" int premvos_global_avgpool_f32(const float* in, int32_t in_ps, int32_
   PV_REQUIRE(c % 4 == 0 && in_ps % 4 == 0 && out_ps % 4 == 0 && in_ps >= c && out_ps >= c,
              "global_avgpool: C and strides must be multiples of 4");
   PV_REQUIRE(premvos::aligned16(in) && premvos::aligned16(out), "global_avgpool: in/out must be 16-byte aligned");
-  hipLaunchKernelGGL(gap_kernel, dim3(grid_for((long)n * (c / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), in,
-                     in_ps, n, hw, c / 4, out, out_ps);
+  if (hw >= 128) {
+    hipLaunchKernelGGL(gap_sliced_kernel, dim3((c / 4 + 31) / 32, n), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                       in_ps, hw, c / 4, out, out_ps);
+  } else {
+    hipLaunchKernelGGL(gap_kernel, dim3(grid_for((long)n * (c / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       in, in_ps, n, hw, c / 4, out, out_ps);
+  }
   return premvos::check_launch("global_avgpool");
 }
 

@@ -188,6 +188,84 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restr
   }
 }
 
+// Register-tiled variant for dilation 1: one thread owns a TR x TW block of output pixels for 4 channels and walks the
+// (TR-1)*STRIDE+3 input rows once; every loaded row feeds all the output rows it touches, and an output row is stored
+// as soon as its third input row has been consumed (so only ~3 accumulator rows are live).  Per output this is
+// NROW*NCOL/(TR*TW) float4 loads (1.9 at 8x4, 1.96 at 5x5) against 4.5 for the row kernel; accumulation order per
+// output (bias, then taps in (ky,kx) order) is the same as in the other two kernels -> identical bits.
+template <bool PRE_RELU, int STRIDE, int TW, int TR>
+__global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __restrict__ in, int in_ps, int n, int h, int w,
+                                                             int c4, const float* __restrict__ wgt,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int out_ps, int ho, int wo, int pt, int pl, int act,
+                                                             int cpad) {
+  constexpr int NCOL = (TW - 1) * STRIDE + 3;
+  constexpr int NROW = (TR - 1) * STRIDE + 3;
+  const int xt = (wo + TW - 1) / TW, yt = (ho + TR - 1) / TR;
+  const long total = (long)n * yt * xt * c4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = idx % c4;
+    long t = idx / c4;
+    const int tx = t % xt;
+    t /= xt;
+    const int ty = t % yt, b = t / yt;
+    const int ox0 = tx * TW, oy0 = ty * TR;
+    float4 k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = *reinterpret_cast<const float4*>(wgt + (long)i * cpad + cg * 4);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + cg * 4);
+    float4 acc[TR][TW];
+#pragma unroll
+    for (int o = 0; o < TR; ++o)
+#pragma unroll
+      for (int q = 0; q < TW; ++q) acc[o][q] = bv;
+    const int ix0 = ox0 * STRIDE - pl, iy0 = oy0 * STRIDE - pt;
+    const float* imgp = in + ((long)b * h * w) * in_ps + cg * 4;
+#pragma unroll
+    for (int j = 0; j < NROW; ++j) {
+      const int iy = iy0 + j;
+      const bool rowok = (unsigned)iy < (unsigned)h;
+      const float* rowp = imgp + ((long)iy * w) * in_ps;
+      float4 v[NCOL];
+#pragma unroll
+      for (int cx = 0; cx < NCOL; ++cx) {
+        const int ix = ix0 + cx;
+        v[cx] = (rowok && (unsigned)ix < (unsigned)w) ? *reinterpret_cast<const float4*>(rowp + (long)ix * in_ps)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRE_RELU) {
+          v[cx].x = fmaxf(v[cx].x, 0.f); v[cx].y = fmaxf(v[cx].y, 0.f);
+          v[cx].z = fmaxf(v[cx].z, 0.f); v[cx].w = fmaxf(v[cx].w, 0.f);
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < TR; ++o) {
+        const int kj = j - o * STRIDE;             // compile-time after unrolling
+        if (kj < 0 || kj > 2) continue;
+#pragma unroll
+        for (int q = 0; q < TW; ++q)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const float4 a = v[q * STRIDE + i], kk = k[kj * 3 + i];
+            acc[o][q].x += a.x * kk.x; acc[o][q].y += a.y * kk.y; acc[o][q].z += a.z * kk.z; acc[o][q].w += a.w * kk.w;
+          }
+        if (kj == 2 && oy0 + o < ho) {             // this output row is complete
+          float* orow = out + (((long)b * ho + oy0 + o) * wo) * out_ps + cg * 4;
+#pragma unroll
+          for (int q = 0; q < TW; ++q) {
+            if (ox0 + q >= wo) break;
+            float4 r = acc[o][q];
+            if (act == PREMVOS_ACT_RELU) {
+              r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(orow + (long)(ox0 + q) * out_ps) = r;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // tf.image.resize_bilinear (TF1): align_corners=True  src = dst*(in-1)/(out-1);  False (legacy) src = dst*in/out
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, int in_ps, int n, int h,
@@ -357,7 +435,31 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
              "dwconv3x3: pointers must be 16-byte aligned");
   PV_REQUIRE(act == PREMVOS_ACT_NONE || act == PREMVOS_ACT_RELU, "dwconv3x3: bad activation");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dilation == 1 && (stride == 1 || stride == 2) && wo >= 8) {   // row-tiled fast path
+  if (dilation == 1 && stride == 1 && wo >= 8 && ho >= 8) {   // register-tiled fast path (stride 2: row kernel wins)
+    // tile: 5x5 when both extents are multiples of 5 and small (the 25x25 maps of the middle/exit flow), else 8 rows
+    // x 4 columns, 4x4 when that leaves the chip short of threads
+    const int c4 = c_pad / 4;
+    int tr = 8, tw = 4;
+    if (ho % 5 == 0 && wo % 5 == 0 && ho <= 50) tr = tw = 5;
+    else if ((long)n * ((ho + 7) / 8) * ((wo + 3) / 4) * c4 < 256L * 1024) tr = 4;
+    const long tot = (long)n * ((ho + tr - 1) / tr) * ((wo + tw - 1) / tw) * c4;
+    const dim3 g(grid_for(tot)), b(256);
+#define PV_DW_TILE(PR, ST, TW_, TR_)                                                                                  \
+  hipLaunchKernelGGL((dwconv3x3_tile_kernel<PR, ST, TW_, TR_>), g, b, 0, s, in, in_ps, n, h, w, c4, wgt, bias, out,   \
+                     out_ps, ho, wo, pt, pl, act, c_pad)
+#define PV_DW_SHAPE(PR, ST)                                                                                           \
+  do {                                                                                                                \
+    if (tr == 5) PV_DW_TILE(PR, ST, 5, 5);                                                                            \
+    else if (tr == 8) PV_DW_TILE(PR, ST, 4, 8);                                                                       \
+    else PV_DW_TILE(PR, ST, 4, 4);                                                                                    \
+  } while (0)
+    if (pre_relu) PV_DW_SHAPE(true, 1);
+    else PV_DW_SHAPE(false, 1);
+#undef PV_DW_SHAPE
+#undef PV_DW_TILE
+    return premvos::check_launch("dwconv3x3_tile");
+  }
+  if (dilation == 1 && (stride == 1 || stride == 2) && wo >= 8) {   // row-tiled path (stride 2, short maps)
     constexpr int TW = 4;
     const long tot = (long)n * ho * ((wo + TW - 1) / TW) * (c_pad / 4);
     const dim3 g(grid_for(tot)), b(256);

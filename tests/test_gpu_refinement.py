@@ -44,6 +44,19 @@ def test_dwconv_matches_torch(c, h, stride, rate, pre, act):
     assert (out.torch().cpu() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("n,hw,c", [(3, 625, 2048), (2, 49, 256), (1, 130, 40)])
+def test_global_avgpool(n, hw, c):
+    """Both kernels of premvos_global_avgpool_f32 (per-thread loop for small maps, sliced for ASPP image pooling)."""
+    _lib, ops = _libops()
+    x = torch.randn((n, hw, 1, c), generator=torch.Generator().manual_seed(hw)).cuda()
+    xi = ops.NHWC.alloc(n, hw, 1, c + 4)
+    xi.buf[..., :c] = x
+    out = torch.zeros((n, c), device="cuda")
+    _lib.check(_lib.load().premvos_global_avgpool_f32(xi.ptr, xi.ps, n, hw, c, out.data_ptr(), c, _lib.current_stream()), "gap")
+    ref = x.double().mean(dim=(1, 2)).float()
+    assert (out - ref).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("align", [0, 1])
 def test_resize_bilinear_tf_semantics(align):
     _lib, ops = _libops()

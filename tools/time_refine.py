@@ -23,6 +23,12 @@ rows = [(a.elapsed_time(b), n) for (a, b), (n, f) in zip(ev, p.steps)]
 tc = sum(ms for ms, n in rows if n.startswith('conv:')); td = sum(ms for ms, n in rows if n.startswith('dw:'))
 db = sum(p.dw_bytes.values())
 print(f"sum eager {sum(r[0] for r in rows):.2f} ms, {len(rows)} launches; conv {tc:.2f} ms ({fl/tc/1e9:.1f} TF/s); dw {td:.2f} ms ({db/td/1e6:.0f} GB/s algorithmic)")
-for ms, n in sorted(rows, reverse=True)[:16]:
+for ms, n in sorted(rows, reverse=True)[:int(os.environ.get('TOP', '16'))]:
     extra = f"{p.flops[n]/ms/1e9:6.1f} TF/s" if n in p.flops else (f"{p.dw_bytes[n]/ms/1e6:6.0f} GB/s" if n in p.dw_bytes else "")
     print(f"  {ms*1e3:9.1f} us  {n:70s} {extra}")
+
+if os.environ.get("NONCONV"):
+    print("non-conv launches:")
+    for ms, n in sorted([r for r in rows if not r[1].startswith("conv:")], reverse=True)[:40]:
+        extra = f"{p.dw_bytes[n]/ms/1e6:6.0f} GB/s" if n in p.dw_bytes else ""
+        print(f"  {ms*1e3:9.1f} us  {n:70s} {extra}")
