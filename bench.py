@@ -122,8 +122,8 @@ def roofline(pipe, batch):
         for i, (a, b) in enumerate(evs):
             samples[i].append(a.elapsed_time(b))
     tot = [sorted(x)[len(x) // 2] for x in samples]          # median per launch: robust to a throttling transient
-    # refinement launches run once per frame of the batch: weight their time by the batch size
-    mult = [batch if st == "refine" else 1 for st, _, _, _ in items]
+    # refinement launches run once per group of frames: weight their time by the calls per step
+    mult = [pipe.refine_calls_per_step if st == "refine" else 1 for st, _, _, _ in items]
     ms = sum(t * m for t, m in zip(tot, mult))
     flops = sum(it[3] for it in items)
     nl = sum(mult)

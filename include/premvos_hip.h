@@ -90,6 +90,8 @@ typedef struct premvos_conv_desc {
   int32_t precision;    /* PREMVOS_PREC_*; bf16 modes: wgt = bf16 hi [cout_pad][k_pad], k_pad % 32 == 0 */
   int32_t stage_k;      /* fp32 path: k depth of an LDS stage, 16 or 32 (0 = library default) */
   const void* wgt_lo;   /* BF16X3: bf16 low parts (w - float(hi)), same shape as wgt */
+  int32_t tail_m_tiles; /* fp32 path, unsplit layers: the last tail_m_tiles rows of BM-tall output tiles are computed  */
+  int32_t tail_split_k; /* as tail_split_k k-slices + fixed-order reduce (fills a partly empty last wave); 0 = off    */
 } premvos_conv_desc;
 
 int premvos_conv2d_f32(const premvos_conv_desc* d, void* stream);

@@ -17,7 +17,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 
 namespace premvos {
-int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s);   // conv_igemm_f32.hip
+int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin);   // conv_igemm_f32.hip
 }
 
 namespace {
@@ -301,7 +301,7 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
       hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per);
       int rc = premvos::check_launch("conv_igemm_bf16(split-k)");
       if (rc) return rc;
-      return premvos::launch_splitk_reduce(d, splits, ncols, s);
+      return premvos::launch_splitk_reduce(d, splits, ncols, s, 0);
     }
     if (d.split_k > 0) return premvos::fail(PREMVOS_EINVAL, "conv2d: split_k=%d needs %ld workspace bytes", d.split_k, need);
   }

@@ -39,7 +39,7 @@ constexpr int BK = 16;           // k granularity of the packed weights (k_pad %
 // KB: k depth of one LDS stage (16 or 32).  Rows are padded by 4 floats (KB+4): 20 and 36 dwords are both 4 x odd,
 // so 16 consecutive rows land on 16 different 16-byte bank slots -> conflict-free ds_read_b128.
 template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     tile_m = v / n_tiles;
     tile_n = v - tile_m * n_tiles;
+    tile_m += mt0;             // tail-split launches start at m-tile row mt0 (0 otherwise)
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
 
   if constexpr (SPLITK) {   // raw partial slab, ncols = gridDim.y * BN (padded: no column predicate needed)
     const int ncols = gridDim.y * BN;
-    float* ws = p.workspace + (long)blockIdx.z * M * ncols;
+    const int mb = mt0 * BM;                  // slabs hold rows [mb, M) only
+    float* ws = p.workspace + (long)blockIdx.z * (M - mb) * ncols;
 #pragma unroll
     for (int ni = 0; ni < NTL; ++ni) {
       const int col = n0 + wn0 + ni * 32 + (lane & 31);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M) ws[(long)m * ncols + col] = acc[mi][ni][r];
+          if (m < M) ws[(long)(m - mb) * ncols + col] = acc[mi][ni][r];
         }
     }
     return;
@@ -249,14 +251,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
 
 // Sum the split-K slabs in fixed order and apply the fused epilogue (bias, residual, activation, layout).
 template <bool PIXSHUF>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const premvos_conv_desc p, const int splits, const int ncols) {
-  const int M = p.n * p.ho * p.wo;
-  const long total = (long)M * p.cout;
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const premvos_conv_desc p, const int splits, const int ncols, const int m_begin) {
+  const int Mt = p.n * p.ho * p.wo - m_begin;      // rows [m_begin, M) were computed as k-slices
+  const long total = (long)Mt * p.cout;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int col = idx % p.cout;
-    const int m = idx / p.cout;
+    const int ml = idx / p.cout;
+    const int m = m_begin + ml;
     float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += p.workspace[((long)z * M + m) * ncols + col];
+    for (int z = 0; z < splits; ++z) v += p.workspace[((long)z * Mt + ml) * ncols + col];
     if (p.bias != nullptr) v += p.bias[col];
     if (p.res != nullptr) v += p.res[(long)m * p.res_ps + col];
     if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -278,14 +281,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const premvos_conv_d
 }  // namespace
 
 namespace premvos {
-int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s) {
-  const long total = (long)d.n * d.ho * d.wo * d.cout;
+int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin) {
+  const long total = ((long)d.n * d.ho * d.wo - m_begin) * d.cout;
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
-    hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(g), dim3(256), 0, s, d, splits, ncols);
+    hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(g), dim3(256), 0, s, d, splits, ncols, m_begin);
   else
-    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(g), dim3(256), 0, s, d, splits, ncols);
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(g), dim3(256), 0, s, d, splits, ncols, m_begin);
   return check_launch("splitk_reduce");
 }
 }  // namespace premvos
@@ -347,30 +350,62 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     const long need = (long)splits * M * ncols * sizeof(float);
     if (splits > 1 && d.workspace != nullptr && (long)d.workspace_bytes >= need) {
       grid.z = splits;
-      hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per);
+      hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per, 0);
       int rc = premvos::check_launch("conv_igemm_f32(split-k)");
       if (rc) return rc;
-      return premvos::launch_splitk_reduce(d, splits, ncols, s);
+      return premvos::launch_splitk_reduce(d, splits, ncols, s, 0);
     }
     if (d.split_k > 0) return premvos::fail(PREMVOS_EINVAL, "conv2d: split_k=%d needs %ld workspace bytes", d.split_k, need);
   }
+  // Tail split: the last `tail_m_tiles` rows of output tiles run as k-slices (+ fixed-order reduce), so that a partly
+  // filled last wave of workgroups (e.g. 588 tiles on 256 CUs: 2 full waves + 76) is spread over the whole chip.
+  int tail = 0, tsplits = 1, tkt_per = 0;
+  if (d.tail_m_tiles > 0 && d.tail_split_k > 1 && d.tail_m_tiles < (int)grid.x) {
+    tkt_per = premvos::cdiv(KT, d.tail_split_k);
+    tsplits = premvos::cdiv(KT, tkt_per);
+    tail = tsplits > 1 ? d.tail_m_tiles : 0;
+    if (tail) {
+      const long mt = (long)M - (long)(grid.x - tail) * BM;
+      const long need = (long)tsplits * mt * grid.y * BN * (long)sizeof(float);
+      if (d.workspace == nullptr || (long)d.workspace_bytes < need)
+        return premvos::fail(PREMVOS_EINVAL, "conv2d: tail split %dx%d needs %ld workspace bytes", d.tail_m_tiles,
+                             d.tail_split_k, need);
+    }
+  }
+  const dim3 gmain(grid.x - tail, grid.y);
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>), grid, block, LDS_BYTES, s, d, 0);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>), gmain, block, LDS_BYTES, s, d, 0, 0);
   else
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>), grid, block, LDS_BYTES, s, d, 0);
-  return premvos::check_launch("conv_igemm_f32");
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>), gmain, block, LDS_BYTES, s, d, 0, 0);
+  int rc = premvos::check_launch("conv_igemm_f32");
+  if (rc || !tail) return rc;
+  const int mt0 = (int)grid.x - tail;
+  hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), dim3(tail, grid.y, tsplits), block, LDS_BYTES,
+                     s, d, tkt_per, mt0);
+  rc = premvos::check_launch("conv_igemm_f32(tail split-k)");
+  if (rc) return rc;
+  return premvos::launch_splitk_reduce(d, tsplits, grid.y * BN, s, mt0 * BM);
 }
 
 template <int BM, int BN, int WM, int WN>
 long ws_cfg(const premvos_conv_desc& d) {
   const int kb = pick_kb(d);
   int splits = pick_splits(d, BM, BN, kb);
-  if (splits <= 1) return 0;
   const int KT = premvos::cdiv(d.k_pad, kb);
-  const int kt_per = premvos::cdiv(KT, splits);
-  splits = premvos::cdiv(KT, kt_per);
-  if (splits <= 1) return 0;
-  return (long)splits * d.n * d.ho * d.wo * premvos::cdiv(d.cout, BN) * BN * (long)sizeof(float);
+  const long M = (long)d.n * d.ho * d.wo;
+  const long ncols = (long)premvos::cdiv(d.cout, BN) * BN;
+  if (splits > 1) {
+    const int kt_per = premvos::cdiv(KT, splits);
+    splits = premvos::cdiv(KT, kt_per);
+    if (splits > 1) return (long)splits * M * ncols * (long)sizeof(float);
+  }
+  const long mtiles = premvos::cdiv((int)M, BM);
+  if (d.tail_m_tiles > 0 && d.tail_split_k > 1 && d.tail_m_tiles < mtiles) {
+    const int kt_per = premvos::cdiv(KT, d.tail_split_k);
+    const int ts = premvos::cdiv(KT, kt_per);
+    if (ts > 1) return (long)ts * (M - (mtiles - d.tail_m_tiles) * BM) * ncols * (long)sizeof(float);
+  }
+  return 0;
 }
 
 inline void pick_tile(const premvos_conv_desc& d, int* bm, int* bn) {
@@ -454,4 +489,4 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
 }
 
 extern "C" const char* premvos_last_error(void) { return premvos::g_err; }
-extern "C" int premvos_abi_version(void) { return 3; }
+extern "C" int premvos_abi_version(void) { return 4; }

@@ -171,6 +171,7 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     d.tile_hint = tile_hint
     d.split_k = split_k
     d.stage_k = stage_k
+    d.tail_m_tiles, d.tail_split_k = 0, 0
     d.workspace, d.workspace_bytes = None, 0
     d.precision = pk.precision
     d.wgt_lo = pk.wgt_lo.data_ptr() if pk.wgt_lo is not None else None
@@ -217,7 +218,20 @@ def _candidates(d: ConvDesc):
         splits = [-1] + ([2, 4] if (nt < 512 and d.k_pad >= 512) else []) + ([8] if (nt < 128 and d.k_pad >= 2048) else [])
         for st in stages:
             for sk in splits:
-                out.append(((bm << 16) | bn, st, sk))
+                out.append(((bm << 16) | bn, st, sk, 0, 0))
+            # tail split (fp32 kernel): keep whole multiples of 256 tiles in the main launch and cut the leftover rows
+            # of tiles along K so they too occupy all CUs
+            mt, ntc = -(-m // bm), -(-d.cout // bn)
+            if d.precision == _lib.PREC_F32 and 256 < nt < 6 * 256 and d.k_pad >= 256:
+                main_rows = (nt // 256) * 256 // ntc
+                tail_rows = mt - main_rows
+                tail_tiles = tail_rows * ntc
+                if main_rows > 0 and 0 < tail_tiles <= 200:
+                    for target in (256, 512):
+                        ts = min(max(2, round(target / tail_tiles)), 16, d.k_pad // 64)
+                        cand = ((bm << 16) | bn, st, -1, tail_rows, ts)
+                        if ts > 1 and cand not in out:
+                            out.append(cand)
     return out
 
 
@@ -235,23 +249,23 @@ def autotune(descs, device="cuda", reps: int = 4):
     cache_file = os.environ.get("PREMVOS_TUNE_CACHE")        # optional: reuse a previous process's choices
     if cache_file and not _TUNE_CACHE and os.path.exists(cache_file):
         import json
-        _TUNE_CACHE.update({tuple(k): tuple(v) for k, v in json.load(open(cache_file))})
+        _TUNE_CACHE.update({tuple(k): tuple(v) + (0,) * (5 - len(v)) for k, v in json.load(open(cache_file))})
     todo = [d for d in descs if _sig(d) not in _TUNE_CACHE]
     if todo:
         need = 0
         for d in todo:
-            for th, st, sk in _candidates(d):
-                d.tile_hint, d.stage_k, d.split_k = th, st, sk
+            for cand in _candidates(d):
+                d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = cand
                 need = max(need, workspace_bytes(d))
         ws = torch.empty(max(need // 4 + 1, 1), dtype=torch.float32, device=device)
         for d in todo:
             sig = _sig(d)
             if sig in _TUNE_CACHE:
                 continue
-            best, best_t = (0, 0, 0), float("inf")
+            best, best_t = (0, 0, 0, 0, 0), float("inf")
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-            for th, st, sk in _candidates(d):
-                d.tile_hint, d.stage_k, d.split_k = th, st, sk
+            for cand in _candidates(d):
+                d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = cand
                 if lib.premvos_conv2d_f32(C.byref(d), stream) != 0:
                     continue
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -262,14 +276,14 @@ def autotune(descs, device="cuda", reps: int = 4):
                 b.synchronize()
                 t = a.elapsed_time(b)
                 if t < best_t:
-                    best, best_t = (th, st, sk), t
+                    best, best_t = cand, t
             _TUNE_CACHE[sig] = best
             d.workspace, d.workspace_bytes = None, 0
         if cache_file:
             import json
             json.dump([[list(k), list(v)] for k, v in _TUNE_CACHE.items()], open(cache_file, "w"))
     for d in descs:
-        d.tile_hint, d.stage_k, d.split_k = _TUNE_CACHE[_sig(d)]
+        d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = _TUNE_CACHE[_sig(d)]
 
 
 def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):

@@ -32,8 +32,11 @@ class FramePipeline:
         self.prop_s = ProposalStage(prop_specific, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True,
                                     precision=precision)
         self.refine = RefinementNet(refine_w, num_middle, device, precision=precision)
-        # a second refinement workspace so two frames of a batch can be in flight on different streams
-        self.n_refine_lanes = min(batch, int(os.environ.get("PREMVOS_REFINE_LANES", "2"))) if concurrent else 1
+        # refinement: the boxes of `refine_group` frames form one batch of the network (bigger GEMMs fill the chip
+        # better); `lanes` independent workspaces let several such calls be in flight on different streams
+        self.refine_group = max(1, min(batch, int(os.environ.get("PREMVOS_REFINE_GROUP", "4"))))
+        n_calls = self.refine_calls_per_step = -(-batch // self.refine_group)
+        self.n_refine_lanes = min(n_calls, int(os.environ.get("PREMVOS_REFINE_LANES", "2"))) if concurrent else 1
         self.masks: Optional[torch.Tensor] = None
         self.conf: Optional[torch.Tensor] = None
         # the four stages of a frame are independent: each replays its HIP graph on its own stream so that the
@@ -48,11 +51,21 @@ class FramePipeline:
         if self.masks is None or self.masks.shape != (B, self.P, H, W):
             self.masks = torch.zeros((B, self.P, H, W), dtype=torch.uint8, device=self.device)
             self.conf = torch.zeros((B, self.P), dtype=torch.float32, device=self.device)
+        G = self.refine_group
+
         def refine_all(lane=0, lanes=1):
-            for i in range(lane, B, lanes):
-                p = self.refine.refine(frames_a[i], boxes_y0x0y1x1[i], max_boxes=self.P, lane=lane)
-                self.masks[i].copy_(p.mask)
-                self.conf[i].copy_(p.conf)
+            for c, i in enumerate(range(0, B, G)):
+                if c % lanes != lane:
+                    continue
+                if G == 1:
+                    p = self.refine.refine(frames_a[i], boxes_y0x0y1x1[i], max_boxes=self.P, lane=lane)
+                    self.masks[i].copy_(p.mask)
+                    self.conf[i].copy_(p.conf)
+                else:
+                    g = min(G, B - i)
+                    p = self.refine.refine_group(frames_a[i:i + g], boxes_y0x0y1x1[i:i + g], lane=lane)
+                    self.masks[i:i + g].copy_(p.mask_g)
+                    self.conf[i:i + g].copy_(p.conf_g)
 
         if not self.concurrent:
             flo = self.flow.run(frames_a, frames_b)
@@ -84,6 +97,7 @@ class FramePipeline:
                                   ("prop_g", self.prop_g.steps, self.prop_g.plan.flops),
                                   ("prop_s", self.prop_s.steps, self.prop_s.plan.flops)):
             out += [(tag, n, f, flops[n]) for n, f in steps if n.startswith("conv:")]
-        rp = self.refine.plan(self.P, *self.masks.shape[2:], False, 0)
-        out += [("refine", n, f, rp.flops[n] * self.batch) for n, f in rp.steps if n.startswith("conv:")]
+        G = self.refine_group
+        rp = self.refine.plan(self.P, *self.masks.shape[2:], False, 0, frames=G)
+        out += [("refine", n, f, rp.flops[n] * self.batch / G) for n, f in rp.steps if n.startswith("conv:")]
         return out

@@ -70,9 +70,13 @@ class PackedDW:
 
 
 class _Plan:
-    def __init__(self, net: "RefinementNet", P: int, H: int, W: int, with_posterior: bool):
+    def __init__(self, net: "RefinementNet", P: int, H: int, W: int, with_posterior: bool, frames: int = 1):
+        """One launch list for ``frames`` frames x ``P`` boxes each: the crops of all frames form ONE batch of the network
+        (bigger GEMM M -> fewer partly filled waves of tiles); crop extraction and un-cropping run per frame."""
         dev, lib = net.device, _lib.load()
-        self.P, self.H, self.W = P, H, W
+        self.P, self.H, self.W, self.G = P, H, W, frames
+        G, PF = frames, P          # PF boxes per frame
+        P = G * PF                 # batch of the network body
         PK, DW = net.packed, net.packed_dw
         steps: List = []
         self.flops: Dict[str, float] = {}
@@ -113,16 +117,19 @@ class _Plan:
             self.dw_bytes[f"dw:{name}"] = 4.0 * k.c * (x.n * x.h * x.w + out.n * out.h * out.w)
 
         S = INPUT_SIZE
-        self.frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
-        self.boxes = torch.zeros((P, 4), dtype=torch.float32, device=dev)       # y0 x0 y1 x1
-        self.count = torch.zeros((1,), dtype=torch.int32, device=dev)
-        self.crops = torch.zeros((P, 4), dtype=torch.int32, device=dev)
+        self.frames = torch.zeros((G, H, W, 3), dtype=torch.uint8, device=dev)
+        self.boxes_g = torch.zeros((G, PF, 4), dtype=torch.float32, device=dev)       # y0 x0 y1 x1
+        self.count = torch.zeros((G,), dtype=torch.int32, device=dev)
+        self.crops = torch.zeros((G, PF, 4), dtype=torch.int32, device=dev)
+        self.frame, self.boxes = self.frames[0], self.boxes_g[0]                      # single-frame views
         self.net_in = alloc(P, S, S, 4)
 
         def mk_input():
-            _lib.check(lib.premvos_refine_input_u8(self.frame.data_ptr(), H, W, self.boxes.data_ptr(),
-                                                   self.count.data_ptr(), P, S, self.net_in.ptr,
-                                                   self.crops.data_ptr(), _lib.current_stream()), "refine_input")
+            for g in range(G):
+                _lib.check(lib.premvos_refine_input_u8(self.frames[g].data_ptr(), H, W, self.boxes_g[g].data_ptr(),
+                                                       self.count[g:].data_ptr(), PF, S,
+                                                       self.net_in.images(g * PF, PF).ptr, self.crops[g].data_ptr(),
+                                                       _lib.current_stream()), "refine_input")
         steps.append(("refine_input", mk_input))
 
         # stem: conv2d_same 3x3 s2 (pad 1 + VALID) and 3x3 s1  (core/xception.py:430-433)
@@ -208,17 +215,21 @@ class _Plan:
         conv(d, "logits/features", self.logits)
 
         # SegmentationSoftmax eval branch + conf_score
-        self.mask = torch.zeros((P, H, W), dtype=torch.uint8, device=dev)
-        self.posterior = torch.zeros((P, H, W), dtype=torch.float32, device=dev) if with_posterior else None
-        self.conf = torch.zeros((P,), dtype=torch.float32, device=dev)
-        wsb = int(lib.premvos_refine_output_workspace_bytes(P, S, H, W))
+        self.mask_g = torch.zeros((G, PF, H, W), dtype=torch.uint8, device=dev)
+        self.posterior_g = torch.zeros((G, PF, H, W), dtype=torch.float32, device=dev) if with_posterior else None
+        self.conf_g = torch.zeros((G, PF), dtype=torch.float32, device=dev)
+        self.mask, self.conf = self.mask_g[0], self.conf_g[0]                         # single-frame views
+        self.posterior = self.posterior_g[0] if with_posterior else None
+        wsb = int(lib.premvos_refine_output_workspace_bytes(PF, S, H, W))
         self.ws = torch.zeros((wsb + 15) // 16 * 4, dtype=torch.float32, device=dev)
 
         def out_layer(lg=self.logits):
-            _lib.check(lib.premvos_refine_output_f32(
-                lg.ptr, lg.ps, lg.h, lg.w, self.crops.data_ptr(), self.count.data_ptr(), P, S, H, W,
-                self.mask.data_ptr(), self.posterior.data_ptr() if self.posterior is not None else None,
-                self.conf.data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
+            for g in range(G):          # stream-ordered, so the frames can share the scratch buffer
+                lgf = lg.images(g * PF, PF)
+                _lib.check(lib.premvos_refine_output_f32(
+                    lgf.ptr, lgf.ps, lgf.h, lgf.w, self.crops[g].data_ptr(), self.count[g:].data_ptr(), PF, S, H, W,
+                    self.mask_g[g].data_ptr(), self.posterior_g[g].data_ptr() if with_posterior else None,
+                    self.conf_g[g].data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
         steps.append(("refine_output", out_layer))
         self.steps, self.buffers = steps, keep
         self.ws_splitk = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)
@@ -268,11 +279,12 @@ class RefinementNet:
                 else:
                     self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device, precision=prec)
 
-    def plan(self, P: int, H: int, W: int, with_posterior: bool = False, lane: int = 0) -> _Plan:
-        """``lane`` selects an independent workspace (same weights) so several frames can be in flight."""
-        key = (P, H, W, with_posterior, lane)
+    def plan(self, P: int, H: int, W: int, with_posterior: bool = False, lane: int = 0, frames: int = 1) -> _Plan:
+        """``lane`` selects an independent workspace (same weights) so several calls can be in flight; ``frames`` > 1
+        builds a plan that refines that many frames (P boxes each) as one batch."""
+        key = (P, H, W, with_posterior, lane, frames)
         if key not in self._plans:
-            p = _Plan(self, P, H, W, with_posterior)
+            p = _Plan(self, P, H, W, with_posterior, frames)
             if self.use_graph:
                 p.capture()
             self._plans[key] = p
@@ -292,6 +304,27 @@ class RefinementNet:
         if n:
             p.boxes[:n].copy_(boxes_y0x0y1x1)
         p.count.fill_(n)
+        if p.graph is not None:
+            p.graph.replay()
+        else:
+            p.run()
+        return p
+
+    def refine_group(self, frames_rgb: torch.Tensor, boxes_y0x0y1x1: torch.Tensor, counts: Optional[torch.Tensor] = None,
+                     with_posterior: bool = False, lane: int = 0) -> _Plan:
+        """Several frames at once: frames uint8 [G,H,W,3], boxes float [G,P,4], counts int32 [G] (default: all P valid).
+        Results in the plan: ``mask_g`` [G,P,H,W], ``conf_g`` [G,P], ``posterior_g``.  Same numbers as G ``refine``
+        calls (each crop is an independent batch element)."""
+        G, H, W, _ = frames_rgb.shape
+        assert boxes_y0x0y1x1.shape[0] == G and boxes_y0x0y1x1.shape[2] == 4
+        P = boxes_y0x0y1x1.shape[1]
+        p = self.plan(P, H, W, with_posterior, lane, frames=G)
+        p.frames.copy_(frames_rgb)
+        p.boxes_g.copy_(boxes_y0x0y1x1)
+        if counts is None:
+            p.count.fill_(P)
+        else:
+            p.count.copy_(counts)
         if p.graph is not None:
             p.graph.replay()
         else:

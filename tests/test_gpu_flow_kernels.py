@@ -210,3 +210,44 @@ def test_deconv_split_k_pixel_shuffle():
     ops.conv2d(_to_nhwc(x, ops), ops.pack_deconv4x4s2(wt, b), out, pad=(1, 1), split_k=4)
     torch.cuda.synchronize()
     assert (out.torch().cpu().double() - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("case", [(3, 200, 25, 25, 200, 1, (128, 128), 32, 4, 3), (2, 96, 31, 40, 72, 3, (64, 128), 16, 9, 4),
+                                  (1, 64, 40, 52, 40, 3, (128, 64), 16, 1, 2)])
+def test_conv2d_tail_split(case):
+    """Tail split: the last rows of output tiles run as k-slices + fixed-order reduce.  Rows of the main launch are
+    bit-identical to the plain kernel, tail rows agree to fp32 round-off, the whole thing is reproducible, and a
+    missing workspace is an error (not a silent fallback)."""
+    from premvos_amd import _lib
+    import ctypes as C
+    ops = _ops()
+    n, cin, h, w, cout, k, (bm, bn), st, tail, ts = case
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    res = torch.randn((n, cout, h, w), generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), padding=k // 2) + res.double())
+    xin, pk, rr = _to_nhwc(x, ops), ops.pack_conv(wt, b), _to_nhwc(res, ops)
+    outs = []
+    for use_tail in (True, True, False):
+        out = _to_nhwc(torch.zeros(ref.shape), ops, coff=1, ps=cout + 3)
+        d = ops.conv_desc(xin, pk, out, pad=(k // 2, k // 2), act=ops.ACT_RELU, res=rr, split_k=-1, stage_k=st,
+                          tile_hint=(bm << 16) | bn)
+        if use_tail:
+            d.tail_m_tiles, d.tail_split_k = tail, ts
+            assert ops.workspace_bytes(d) > 0
+            assert _lib.load().premvos_conv2d_f32(C.byref(d), _lib.current_stream()) != 0     # no workspace -> error
+            assert "workspace" in _lib.load().premvos_last_error().decode()
+        ws = ops.assign_workspace([d])          # noqa: F841
+        ops.run_desc(d)
+        torch.cuda.synchronize()
+        outs.append(out.torch().cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].double() - ref).abs().max().item() < 2e-4
+    m = n * h * w
+    main_rows = (-(-m // bm) - tail) * bm
+    flat = [o.permute(0, 2, 3, 1).reshape(m, cout) for o in outs]
+    assert torch.equal(flat[0][:main_rows], flat[2][:main_rows])
+    assert (flat[0][main_rows:] - flat[2][main_rows:]).abs().max().item() < 1e-4
+    assert not torch.equal(flat[0][main_rows:], torch.zeros_like(flat[0][main_rows:]))

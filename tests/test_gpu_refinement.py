@@ -153,6 +153,34 @@ def test_refinement_net_end_to_end(use_graph):
     assert int(p.mask[len(BOXES):].sum()) == 0
 
 
+def test_refine_group_equals_per_frame_calls():
+    """Three frames refined as ONE batch (refine_group) == three refine() calls (each crop is an independent batch
+    element; ragged per-frame box counts).  A different batch size may pick a different k-split, i.e. another fp32
+    summation order, hence 1e-5 on posteriors / conf instead of bit equality; masks may differ only at p ~ 0.5."""
+    from premvos_amd.refinement import RefinementNet
+    nm = 1
+    net = RefinementNet(R.synth_weights(3, nm), nm)
+    rng = np.random.default_rng(7)
+    frames = torch.from_numpy(rng.integers(0, 256, (3, 100, 160, 3), dtype=np.uint8)).cuda()
+    boxes = torch.zeros((3, 4, 4))
+    counts = [4, 2, 0]
+    for g in range(3):
+        for i in range(counts[g]):
+            y0, x0 = rng.uniform(0, 50), rng.uniform(0, 90)
+            boxes[g, i] = torch.tensor([y0, x0, y0 + rng.uniform(10, 45), x0 + rng.uniform(10, 65)])
+    boxes = boxes.cuda()
+    pg = net.refine_group(frames, boxes, torch.tensor(counts, dtype=torch.int32).cuda(), with_posterior=True)
+    mg, cg, qg = pg.mask_g.clone(), pg.conf_g.clone(), pg.posterior_g.clone()
+    for g in range(3):
+        p1 = net.refine(frames[g], boxes[g, :counts[g]], max_boxes=4, with_posterior=True)
+        n = counts[g]
+        assert (qg[g, :n] - p1.posterior[:n]).abs().max().item() < 1e-5 if n else True
+        assert (cg[g, :n] - p1.conf[:n]).abs().max().item() < 1e-5 if n else True
+        diff = mg[g] != p1.mask
+        assert not bool(diff.any()) or (p1.posterior[diff] - 0.5).abs().max().item() < 1e-4
+        assert int(mg[g, counts[g]:].sum()) == 0
+
+
 def test_refinement_engine_json_contract(tmp_path):
     from premvos_amd import rle
     from premvos_amd.refinement import RefinementEngine, RefinementNet

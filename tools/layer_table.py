@@ -20,7 +20,7 @@ for _ in range(5):
     for i, (a, b) in enumerate(evs): samples[i].append(a.elapsed_time(b))
 rows = []
 for (st, name, fn, fl), sm in zip(items, samples):
-    ms = sorted(sm)[2]; mult = B if st == "refine" else 1
+    ms = sorted(sm)[2]; mult = pipe.refine_calls_per_step if st == "refine" else 1
     per = fl / mult
     rows.append((ms * mult - fl / 120e9, st, name, ms, per / ms / 1e9, mult))
 tot = sum(r[3] * r[5] for r in rows); lost = sum(r[0] for r in rows)
