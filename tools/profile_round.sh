@@ -1,0 +1,40 @@
+#!/bin/bash
+# Regenerates the judged evidence of a round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r01      -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
+# 1. tuned-configuration cache + the default bench line   2. rocprofv3 kernel stats, serial and concurrent stages
+# 3. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) -> HBM bytes per conv launch
+set -u
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out
+mkdir -p "$OUT"
+export PREMVOS_TUNE_CACHE=$OUT/${TAG}_tune_choices.json
+rm -f "$PREMVOS_TUNE_CACHE"
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1      # fills the tune cache
+REPO=$PWD
+cd /tmp && export TMPDIR=/tmp
+for mode in serial concurrent; do
+  [ $mode = serial ] && export PREMVOS_PIPELINE_SERIAL=1 || unset PREMVOS_PIPELINE_SERIAL
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof_$mode" -o bench -- \
+    python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_prof_$mode.log" 2>&1
+  grep '^{' "$OUT/${TAG}_prof_$mode.log" | tail -1 > "$OUT/${TAG}_bench_under_rocprof_$mode.json"
+done
+export PREMVOS_PIPELINE_SERIAL=1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_$c" -o pmc -- \
+    python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/${TAG}_pmc_$c.log" 2>&1
+done
+unset PREMVOS_PIPELINE_SERIAL
+cd "$REPO"
+python tools/pmc_traffic.py "$(find $OUT/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" \
+  "$(find $OUT/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_conv_hbm_traffic.json" \
+  > /dev/null
+cp "$OUT/${TAG}_conv_hbm_traffic.json" profiles/${TAG}_conv_hbm_traffic.json      # bench.py reads the traffic figure from here
+python bench.py > "$OUT/${TAG}_bench_fp32.log" 2>&1
+grep '^{' "$OUT/${TAG}_bench_fp32.log" | tail -1 > "$OUT/${TAG}_bench_fp32.json"
+# keep only the small summaries (the traces are tens of MB)
+for mode in serial concurrent; do
+  cp "$(find $OUT/${TAG}_prof_$mode -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_fp32_${mode}_kernel_stats.csv"
+  rm -rf "$OUT/${TAG}_prof_$mode"
+done
+rm -rf "$OUT/${TAG}_pmc_FETCH_SIZE" "$OUT/${TAG}_pmc_WRITE_SIZE"
+cat "$OUT/${TAG}_bench_fp32.json"
