@@ -114,7 +114,7 @@ def roofline(pipe, batch):
     samples = [[] for _ in items]
     for _ in range(reps):
         evs = []
-        for _, _, fn, _ in items:
+        for _, _, fn, _, _ in items:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); fn(); b.record()
             evs.append((a, b))
@@ -123,25 +123,28 @@ def roofline(pipe, batch):
             samples[i].append(a.elapsed_time(b))
     tot = [sorted(x)[len(x) // 2] for x in samples]          # median per launch: robust to a throttling transient
     # refinement launches run once per group of frames: weight their time by the calls per step
-    mult = [pipe.refine_calls_per_step if st == "refine" else 1 for st, _, _, _ in items]
+    mult = [pipe.refine_calls_per_step if st == "refine" else 1 for st, _, _, _, _ in items]
     ms = sum(t * m for t, m in zip(tot, mult))
     flops = sum(it[3] for it in items)
     nl = sum(mult)
     ach = flops / (ms * 1e-3) / 1e12
     per_stage = {}
-    for (st, _, _, f), t, m in zip(items, tot, mult):
+    for (st, _, _, f, _), t, m in zip(items, tot, mult):
         a = per_stage.setdefault(st, [0.0, 0.0])
         a[0] += f
         a[1] += t * m
     traffic = None      # HBM bytes per launch from the PMC passes (profiles/r01_conv_hbm_traffic.json: method + corrections)
-    tf = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
-    if batch == 4 and os.path.exists(tf):
+    import glob
+    tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_hbm_traffic.json")))      # newest round last
+    if batch == 4 and tfs:
         try:
-            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
+            traffic = round(json.load(open(tfs[-1]))["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
+    alg_bytes = sum(it[4] for it in items)
     return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(alg_bytes / nl),
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),
             "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
 

@@ -178,6 +178,14 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     return d
 
 
+def algorithmic_bytes(d: ConvDesc) -> float:
+    """Compulsory HBM bytes of one conv launch: every input pixel the taps touch once, weights once, output (+ residual)
+    once -- what the PMC traffic figure of bench.py's roofline is compared with."""
+    m = d.n * d.ho * d.wo
+    pix_in = min(d.n * d.h * d.w, m * d.kh * d.kw)
+    return 4.0 * (pix_in * d.cin + m * d.cout * (2 if d.res else 1) + d.cout * d.kh * d.kw * d.cin)
+
+
 def workspace_bytes(d: ConvDesc) -> int:
     return int(_lib.load().premvos_conv2d_workspace_bytes(C.byref(d)))
 

@@ -91,13 +91,16 @@ class FramePipeline:
                 "specific_boxes": ps.final_boxes, "specific_probs": ps.final_probs, "specific_count": ps.final_count}
 
     def conv_steps(self):
-        """(stage, name, launch fn, algorithmic FLOPs) of every conv_igemm launch of one step (bench roofline)."""
+        """(stage, name, launch fn, algorithmic FLOPs per step, algorithmic HBM bytes per step) of every conv_igemm launch
+        of one step (bench roofline)."""
+        from . import ops
         out = []
-        for tag, steps, flops in (("flow", self.flow.steps, self.flow.plan.flops),
-                                  ("prop_g", self.prop_g.steps, self.prop_g.plan.flops),
-                                  ("prop_s", self.prop_s.steps, self.prop_s.plan.flops)):
-            out += [(tag, n, f, flops[n]) for n, f in steps if n.startswith("conv:")]
         G = self.refine_group
         rp = self.refine.plan(self.P, *self.masks.shape[2:], False, 0, frames=G)
-        out += [("refine", n, f, rp.flops[n] * self.batch / G) for n, f in rp.steps if n.startswith("conv:")]
+        for tag, steps, plan, mult in (("flow", self.flow.steps, self.flow.plan, 1), ("prop_g", self.prop_g.steps, self.prop_g.plan, 1),
+                                       ("prop_s", self.prop_s.steps, self.prop_s.plan, 1),
+                                       ("refine", rp.steps, rp, self.refine_calls_per_step)):
+            conv = [(n, f) for n, f in steps if n.startswith("conv:")]
+            assert len(conv) == len(plan.descs)
+            out += [(tag, n, f, plan.flops[n] * mult, ops.algorithmic_bytes(d) * mult) for (n, f), d in zip(conv, plan.descs)]
         return out

@@ -101,11 +101,111 @@ def _boxes_from_proposals(proposals: List[dict]) -> np.ndarray:
     return out
 
 
+class Extractions:
+    """Key names of refinement_net/core/Extractions.py:1-6."""
+    EXTRACTIONS = "extractions"
+    SEGMENTATION_POSTERIORS = "segmentation_posteriors"
+    SEGMENTATION_POSTERIORS_ORIGINAL_SIZE = "segmentation_posteriors_original_size"
+    SEGMENTATION_MASK_ORIGINAL_SIZE = "segmentation_mask_original_size"
+    SEGMENTATION_MASK_INPUT_SIZE = "segmentation_mask_input_size"
+
+
+class DataKeys:
+    """The keys of refinement_net/datasets/DataKeys.py the feed dataset uses."""
+    IMAGES = "images"
+    SEGMENTATION_LABELS = "segmentation_labels"
+    IMAGE_FILENAMES = "image_filenames"
+    BBOXES_y0x0y1x1 = "bboxes_y0x0y1x1"
+    OBJ_TAGS = "obj_tags"
+
+
+MEASURES = "measures"          # core/Measures.py
+
+
+class _FeedData:
+    """``engine.valid_data`` of the reference (FewShotFeedSegmentationDataset.py:24-51): the per-image example table and
+    the per-box "feed dict".  Here a feed dict just names (table, index); the table additionally remembers the uint8
+    frame so the engine can refine ALL its boxes in one batched GPU pass the first time any of them is asked for."""
+
+    def set_up_data_for_image(self, image, boxes):
+        obj_data = {}
+        frame_u8 = np.ascontiguousarray(np.asarray(image)[:, :, :3], dtype=np.uint8)
+        image = image / 255
+        label = np.zeros(image.shape[:2] + (1,), dtype=np.uint8)
+        for box_id, box in enumerate(boxes):
+            x0, y0, x1, y1 = box
+            x1 = x1 + x0
+            y1 = y1 + y0
+            obj_data[box_id] = {DataKeys.IMAGES: image, DataKeys.SEGMENTATION_LABELS: label, DataKeys.IMAGE_FILENAMES: "",
+                                DataKeys.BBOXES_y0x0y1x1: [y0, x0, y1, x1], DataKeys.OBJ_TAGS: str(box_id)}
+        if len(obj_data) > 0:
+            self._frames[id(obj_data)] = (obj_data, frame_u8)        # keeps obj_data alive while it is the current image
+            while len(self._frames) > 2:
+                self._frames.pop(next(iter(self._frames)))
+            return obj_data
+        return None
+
+    def __init__(self):
+        self._frames: "OrderedDict[int, tuple]" = OrderedDict()
+
+    def get_feed_dict_for_next_step(self, image_data, bbox_idx):
+        assert bbox_idx in image_data, bbox_idx
+        return {"image_data": image_data, "bbox_idx": bbox_idx}
+
+
+class _FeedTrainer:
+    """``engine.trainer`` of the reference: ``validation_step(feed_dict=..., extraction_keys=[...])`` ->
+    {"measures": {}, "extractions": {key: [array[1, ...]]}}   (core/Trainer.py:128-169, Extractions.py:9-23)."""
+
+    def __init__(self, engine: "RefinementEngine"):
+        self._engine = engine
+        self._cache = (None, None)
+        self.validation_step_number = 0
+
+    def validation_step(self, epoch=None, feed_dict=None, extraction_keys=()):
+        image_data, idx = feed_dict["image_data"], feed_dict["bbox_idx"]
+        if self._cache[0] is not image_data:
+            entry = self._engine.valid_data._frames.get(id(image_data))
+            if entry is not None and entry[0] is image_data:
+                frame = entry[1]
+            else:                                                          # table built by someone else: recover the frame
+                frame = np.rint(np.asarray(image_data[idx][DataKeys.IMAGES]) * 255).astype(np.uint8)
+            boxes = np.array([image_data[i][DataKeys.BBOXES_y0x0y1x1] for i in range(len(image_data))], np.float32)
+            self._cache = (image_data, self._engine.refine_boxes(frame, boxes))
+        masks, post, _ = self._cache[1]
+        self.validation_step_number += 1
+        ex = {Extractions.SEGMENTATION_MASK_ORIGINAL_SIZE: [masks[idx:idx + 1].astype(np.int64)],
+              Extractions.SEGMENTATION_POSTERIORS_ORIGINAL_SIZE: [post[idx:idx + 1]],
+              DataKeys.OBJ_TAGS: [np.array([image_data[idx][DataKeys.OBJ_TAGS].encode("utf-8")])]}
+        return {MEASURES: {}, Extractions.EXTRACTIONS: {k: v for k, v in ex.items() if k in extraction_keys}}
+
+
 class RefinementEngine:
-    """What MergeTrack holds as ``engine``: refines all proposals of a frame in one batched pass."""
+    """What MergeTrack holds as ``engine``: refines all proposals of a frame in one batched pass.  ``valid_data`` and
+    ``trainer`` reproduce the reference engine's call shapes, so MergeTrack/refinement_net_functions.py:38-64 runs
+    against this object unchanged (its per-box loop then reads results of ONE batched pass per image)."""
 
     def __init__(self, net: RefinementNet, max_boxes: int = 40):
         self.net, self.max_boxes = net, max_boxes
+        self.valid_data = _FeedData()
+        self.trainer = _FeedTrainer(self)
+
+    def refine_boxes(self, frame_u8: np.ndarray, boxes_y0x0y1x1: np.ndarray):
+        """-> (mask uint8 [n,H,W], posterior f32 [n,H,W], conf f32 [n]) as numpy."""
+        n = len(boxes_y0x0y1x1)
+        H, W = frame_u8.shape[:2]
+        masks = np.zeros((n, H, W), np.uint8)
+        post = np.zeros((n, H, W), np.float32)
+        conf = np.zeros((n,), np.float32)
+        frame = torch.from_numpy(np.ascontiguousarray(frame_u8[:, :, :3])).to(self.net.device)
+        for s in range(0, n, self.max_boxes):
+            chunk = np.asarray(boxes_y0x0y1x1[s:s + self.max_boxes], np.float32)
+            P = self.max_boxes if n > self.max_boxes else _bucket(len(chunk))
+            p = self.net.refine(frame, torch.from_numpy(chunk).to(self.net.device), max_boxes=P, with_posterior=True)
+            masks[s:s + len(chunk)] = p.mask[:len(chunk)].cpu().numpy()
+            post[s:s + len(chunk)] = p.posterior[:len(chunk)].cpu().numpy()
+            conf[s:s + len(chunk)] = p.conf[:len(chunk)].cpu().numpy()
+        return masks, post, conf
 
     def refine_frame(self, image_rgb: np.ndarray, proposals: List[dict]) -> List[dict]:
         if not proposals:

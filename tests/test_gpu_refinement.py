@@ -198,3 +198,39 @@ def test_refinement_engine_json_contract(tmp_path):
         assert a["segmentation"]["size"] == [90, 140]
         ma, mb = rle.decode(a["segmentation"]), R.rle_decode(b["segmentation"])
         assert (ma != mb).mean() < 2e-3
+
+
+def test_engine_exposes_the_reference_feed_api():
+    """MergeTrack drives the engine box by box through valid_data / trainer.validation_step
+    (MergeTrack/refinement_net_functions.py:38-64); the same sequence of calls on this engine must yield, per box, the
+    [1,H,W] mask / posterior arrays and the byte-string object tag -- and the same numbers as the batched entry point."""
+    from premvos_amd import rle
+    from premvos_amd.refinement import DataKeys, Extractions, RefinementEngine, RefinementNet
+    nm = 1
+    w = R.synth_weights(2, nm)
+    img = (np.random.default_rng(5).random((90, 140, 3)) * 255).astype(np.uint8)
+    props = [{"bbox": [10.5, 20.0, 60.0, 40.5], "score": 0.91}, {"bbox": [70.0, 5.0, 50.0, 80.0], "score": 0.5},
+             {"bbox": [0.0, 0.0, 30.0, 30.0], "score": 0.7}]
+    eng = RefinementEngine(RefinementNet(w, nm))
+    batched = eng.refine_frame(img, [dict(p) for p in props])
+
+    data = eng.valid_data
+    table = data.set_up_data_for_image(img, [p["bbox"] for p in props])
+    assert sorted(table) == [0, 1, 2] and table[1][DataKeys.BBOXES_y0x0y1x1] == [5.0, 70.0, 85.0, 120.0]
+    assert table[0][DataKeys.IMAGES].dtype == np.float64 and table[0][DataKeys.IMAGES].max() <= 1.0
+    keys = [Extractions.SEGMENTATION_POSTERIORS_ORIGINAL_SIZE, Extractions.SEGMENTATION_MASK_ORIGINAL_SIZE, DataKeys.OBJ_TAGS]
+    for idx in (2, 0, 1):                       # any order
+        res = eng.trainer.validation_step(feed_dict=data.get_feed_dict_for_next_step(table, idx), extraction_keys=keys)
+        ex = res[Extractions.EXTRACTIONS]
+        assert set(ex) == set(keys) and all(len(v) == 1 and v[0].shape[0] == 1 for v in ex.values())
+        tag = int(ex[DataKeys.OBJ_TAGS][0][0].decode("utf-8"))
+        assert tag == idx
+        mask = ex[Extractions.SEGMENTATION_MASK_ORIGINAL_SIZE][0][0]
+        post = ex[Extractions.SEGMENTATION_POSTERIORS_ORIGINAL_SIZE][0][0]
+        assert mask.shape == post.shape == (90, 140) and post.dtype == np.float32
+        assert np.array_equal(rle.decode(rle.encode(mask.astype("uint8") * 255)), rle.decode(batched[idx]["segmentation"]))
+        conf = np.where(mask == 0, 1 - post, post)
+        assert abs(float((2 * conf - 1).mean()) - float(batched[idx]["conf_score"])) < 1e-5
+    assert set(eng.trainer.validation_step(feed_dict=data.get_feed_dict_for_next_step(table, 0),
+                                           extraction_keys=[DataKeys.OBJ_TAGS])[Extractions.EXTRACTIONS]) == {DataKeys.OBJ_TAGS}
+    assert data.set_up_data_for_image(img, []) is None

@@ -13,13 +13,13 @@ items = pipe.conv_steps()
 samples = [[] for _ in items]
 for _ in range(5):
     evs = []
-    for _, _, fn, _ in items:
+    for _, _, fn, _, _ in items:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); evs.append((a, b))
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(evs): samples[i].append(a.elapsed_time(b))
 rows = []
-for (st, name, fn, fl), sm in zip(items, samples):
+for (st, name, fn, fl, _), sm in zip(items, samples):
     ms = sorted(sm)[2]; mult = pipe.refine_calls_per_step if st == "refine" else 1
     per = fl / mult
     rows.append((ms * mult - fl / 120e9, st, name, ms, per / ms / 1e9, mult))
