@@ -249,6 +249,28 @@ int premvos_refine_output_f32(const float* logits, int32_t logits_ps, int32_t lh
  * which premvos_amd/weights.py reads and writes without TensorFlow (proposal_net/train.py:655, core/Saver.py:33-48). */
 uint32_t premvos_crc32c_host(const void* data, int64_t n);
 
+/* ------------------------------------------------------------------------------------------
+ * MergeTrack-side mask helpers (the consumer of the hot path).  Masks are uint8 [n][h][w] row-major,
+ * nonzero = foreground, resident in HBM.
+ * ---------------------------------------------------------------------------------------- */
+/* MergeTrack/merge_functions.py:209-217 warp_flow: out = cv2.remap(mask, grid - flow, INTER_LINEAR) (uint8 fixed-point
+ * path, zero border), then (== 1) when binarize != 0.  flow: float [h][w][2] = (u, v) as in the .flo payload. */
+int premvos_mask_warp_u8(const uint8_t* masks, int32_t n, int32_t h, int32_t w, const float* flow, uint8_t* out,
+                         int32_t binarize, void* stream);
+
+/* merge_functions.py:38-45 (pycocotools iou on the proposals' RLEs): pixel counts of every pair --
+ * inter[ib*na + ia] = |a_ia AND b_ib|, area_a[ia], area_b[ib]; the caller forms i/u in double (u = 1 when i == 0). */
+int premvos_mask_overlap_u8(const uint8_t* a, int32_t na, const uint8_t* b, int32_t nb, int64_t hw, int64_t* inter,
+                            int64_t* area_a, int64_t* area_b, void* stream);
+
+/* merge_functions.py:224-226 (pycocotools encode of the Fortran-ordered mask): ascending column-major positions
+ * q = x*h + y at which the value changes (value before q = 0 is background) -> positions[i*capacity ..], nruns[i] =
+ * number of changes (may exceed capacity: then only the first `capacity` are stored).  COCO counts = successive
+ * differences of [0, positions..., h*w]. */
+int64_t premvos_rle_workspace_bytes(int32_t n, int32_t h, int32_t w);
+int premvos_rle_boundaries_u8(const uint8_t* masks, int32_t n, int32_t h, int32_t w, int32_t* positions,
+                              int32_t capacity, int32_t* nruns, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

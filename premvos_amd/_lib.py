@@ -64,6 +64,9 @@ SIGNATURES = {
     "premvos_resize_bilinear_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "premvos_broadcast_pixel_f32": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "premvos_refine_output_f32": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "premvos_mask_warp_u8": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
+    "premvos_mask_overlap_u8": [_vp, _i32, _vp, _i32, C.c_int64, _vp, _vp, _vp, _vp],
+    "premvos_rle_boundaries_u8": [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "premvos_frcnn_tail_f32": [_vp, _i32, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32,
                                _f32, _vp, _vp, _vp, _vp, _vp],
 }
@@ -105,6 +108,8 @@ def load():
     lib.premvos_crc32c_host.restype = C.c_uint32
     lib.premvos_refine_output_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
     lib.premvos_refine_output_workspace_bytes.restype = C.c_int64
+    lib.premvos_rle_workspace_bytes.argtypes = [_i32, _i32, _i32]
+    lib.premvos_rle_workspace_bytes.restype = C.c_int64
     _LIB = lib
     return lib
 

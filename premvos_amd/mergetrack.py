@@ -1,0 +1,122 @@
+"""Device-side counterparts of the mask work MergeTrack does per frame on the hot path's outputs:
+
+  ``warp_flow`` / ``warp_proposals``   MergeTrack/merge_functions.py:209-241   (cv2.remap + == 1, RLE, bbox, scores)
+  ``mask_iou``                         the pycocotools ``iou`` of merge_functions.py:38-45 on masks in HBM
+  ``encode_masks``                     pycocotools ``encode(np.asfortranarray(mask))`` with ``counts`` as str
+
+Same names, argument meaning and return shapes as the reference functions; masks may be numpy arrays (copied in) or
+uint8 CUDA tensors (used in place).  Everything that touches pixels runs in libpremvos_hip.so (no CPU fallback);
+only run-length differencing and the ASCII packing of ``counts`` happen on the host, on a few hundred integers.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib, rle
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+def _dev_masks(masks, device="cuda") -> torch.Tensor:
+    """-> uint8 [n,h,w] contiguous CUDA tensor."""
+    if isinstance(masks, torch.Tensor):
+        t = masks
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(m) for m in masks]) if isinstance(masks, (list, tuple))
+                                                  else np.asarray(masks)))
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    assert t.dim() == 3, t.shape
+    return t.to(device=device, dtype=torch.uint8).contiguous()
+
+
+def get_flow(filename: str) -> np.ndarray:
+    """merge_functions.py:197-207."""
+    from .flow.driver import readFlowFile
+    return readFlowFile(filename)
+
+
+def warp_masks(masks: ArrayLike, flow: ArrayLike, binarize: bool = True) -> torch.Tensor:
+    """All masks of a frame by one flow field, on the GPU: uint8 [n,h,w] -> uint8 [n,h,w] (stays in HBM)."""
+    _lib.require_gpu()
+    m = _dev_masks(masks)
+    f = (flow if isinstance(flow, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(flow, dtype=np.float32)))
+    f = f.to(device=m.device, dtype=torch.float32).contiguous()
+    n, h, w = m.shape
+    assert f.shape == (h, w, 2), (f.shape, m.shape)
+    out = torch.empty_like(m)
+    _lib.check(_lib.load().premvos_mask_warp_u8(m.data_ptr(), n, h, w, f.data_ptr(), out.data_ptr(), int(binarize),
+                                                _lib.current_stream()), "mask_warp")
+    return out
+
+
+def warp_flow(img: np.ndarray, flow: np.ndarray, binarize: bool = True) -> np.ndarray:
+    """merge_functions.py:209-217 for one uint8 image (numpy in, numpy out)."""
+    return warp_masks(np.asarray(img)[None], flow, binarize)[0].cpu().numpy()
+
+
+def mask_overlap(a: ArrayLike, b: ArrayLike):
+    """-> (inter int64 [nb,na], area_a int64 [na], area_b int64 [nb]) as CUDA tensors."""
+    _lib.require_gpu()
+    ma, mb = _dev_masks(a), _dev_masks(b)
+    assert ma.shape[1:] == mb.shape[1:], (ma.shape, mb.shape)
+    na, nb = ma.shape[0], mb.shape[0]
+    inter = torch.empty((nb, na), dtype=torch.int64, device=ma.device)
+    aa = torch.empty((na,), dtype=torch.int64, device=ma.device)
+    ab = torch.empty((nb,), dtype=torch.int64, device=ma.device)
+    _lib.check(_lib.load().premvos_mask_overlap_u8(ma.data_ptr(), na, mb.data_ptr(), nb, ma.shape[1] * ma.shape[2],
+                                                   inter.data_ptr(), aa.data_ptr(), ab.data_ptr(),
+                                                   _lib.current_stream()), "mask_overlap")
+    return inter, aa, ab
+
+
+def mask_iou(dt: ArrayLike, gt: ArrayLike) -> np.ndarray:
+    """``pycocotools.mask.iou(dt, gt, [0]*len(gt))`` on masks: float64 [len(dt), len(gt)]; 0 where disjoint."""
+    inter, aa, ab = mask_overlap(dt, gt)
+    i = inter.cpu().numpy().astype(np.float64).T                       # [na, nb]
+    u = aa.cpu().numpy()[:, None].astype(np.float64) + ab.cpu().numpy()[None, :].astype(np.float64) - i
+    return np.where(i > 0, i / np.where(i > 0, u, 1.0), 0.0)
+
+
+def encode_masks(masks: ArrayLike) -> List[Dict[str, object]]:
+    """COCO RLE of every mask ({"size": [h, w], "counts": str}); run boundaries are found on the GPU."""
+    _lib.require_gpu()
+    m = _dev_masks(masks)
+    n, h, w = m.shape
+    lib = _lib.load()
+    cap = 4096
+    ws = torch.empty((int(lib.premvos_rle_workspace_bytes(n, h, w)) + 3) // 4, dtype=torch.int32, device=m.device)
+    nruns = torch.empty((n,), dtype=torch.int32, device=m.device)
+    while True:
+        pos = torch.empty((n, cap), dtype=torch.int32, device=m.device)
+        _lib.check(lib.premvos_rle_boundaries_u8(m.data_ptr(), n, h, w, pos.data_ptr(), cap, nruns.data_ptr(),
+                                                 ws.data_ptr(), _lib.current_stream()), "rle_boundaries")
+        cnt = nruns.cpu().numpy()
+        if int(cnt.max()) <= cap:
+            break
+        cap = int(cnt.max())                      # a very ragged mask: one retry with the exact capacity
+    posh = pos.cpu().numpy()
+    out = []
+    for i in range(n):
+        edges = np.concatenate([[0], posh[i, :cnt[i]].astype(np.int64), [h * w]])
+        out.append({"size": [int(h), int(w)], "counts": rle.counts_to_string(np.diff(edges))})
+    return out
+
+
+def warp_proposals(proposals: Sequence[Dict], optflow: Union[str, ArrayLike]) -> List[Dict]:
+    """merge_functions.py:219-241: every proposal's 'mask' warped to the next frame, with its RLE, bbox and scores.
+    ``optflow`` is a .flo filename (as in the reference) or a flow array / CUDA tensor [h,w,2]."""
+    flow = get_flow(optflow) if isinstance(optflow, str) else optflow
+    if not proposals:
+        return []
+    warped = warp_masks([p["mask"] for p in proposals], flow)
+    segs = encode_masks(warped)
+    wm = warped.cpu().numpy()
+    out = []
+    for i, p in enumerate(proposals):
+        out.append({"segmentation": segs[i], "bbox": rle.to_bbox(segs[i]), "score": 0.5 * (p["final_score"] + 1),
+                    "final_score": p["final_score"], "object_score": p["object_score"], "mask": wm[i], "id": p["id"]})
+    return out

@@ -1,0 +1,129 @@
+"""GPU parity of the MergeTrack-side mask helpers (premvos_amd/mergetrack.py) with oracle/merge_oracle.py and
+premvos_amd/rle.py -- integer work, so everything is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import merge_oracle as M  # noqa: E402
+from premvos_amd import rle  # noqa: E402
+
+
+def _masks(seed, n, h, w, blobs=True):
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n, h, w), np.uint8)
+    yy, xx = np.mgrid[:h, :w]
+    for i in range(n):
+        if blobs:
+            for _ in range(3):
+                cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(2, max(h, w) / 3)
+                out[i] |= ((yy - cy) ** 2 + (xx - cx) ** 2 < r * r).astype(np.uint8)
+        else:
+            out[i] = rng.random((h, w)) > 0.5
+    return out
+
+
+def _flow(seed, h, w, mag):
+    rng = np.random.default_rng(seed)
+    f = rng.normal(0, mag, (h, w, 2)).astype(np.float32)
+    f[::3, ::5] = np.round(f[::3, ::5] * 64) / 64            # many exact 1/64 positions: the rounding ties of cvRound
+    f[1::7, 2::3] = np.round(f[1::7, 2::3])                   # integer displacements
+    return f
+
+
+@pytest.mark.parametrize("h,w,mag,blobs", [(37, 53, 2.0, False), (64, 48, 40.0, True), (9, 300, 0.3, False)])
+@pytest.mark.parametrize("binarize", [True, False])
+def test_mask_warp_bit_exact(h, w, mag, blobs, binarize):
+    from premvos_amd import mergetrack as MT
+    m = _masks(h, 4, h, w, blobs)
+    if not binarize:
+        m = (m * np.random.default_rng(1).integers(1, 256, m.shape)).astype(np.uint8)      # general uint8 images
+    f = _flow(w, h, w, mag)
+    got = MT.warp_masks(m, f, binarize).cpu().numpy()
+    for i in range(len(m)):
+        assert np.array_equal(got[i], M.warp_flow(m[i], f, binarize)), i
+    assert np.array_equal(MT.warp_flow(m[0], f, binarize), got[0])
+
+
+def test_mask_warp_extreme_flows():
+    from premvos_amd import mergetrack as MT
+    m = _masks(5, 2, 20, 30, False)
+    f = np.zeros((20, 30, 2), np.float32)
+    f[:10] = 1e6
+    f[10:, :15] = -1e6
+    f[10:, 15:] = 0.999
+    got = MT.warp_masks(m, f).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], M.warp_flow(m[i], f))
+    assert got[:, :10].sum() == 0
+
+
+def test_mask_iou_matches_oracle_and_pycocotools_conventions():
+    from premvos_amd import mergetrack as MT
+    a = _masks(1, 5, 45, 61)
+    b = _masks(2, 3, 45, 61)
+    a[4] = 0                                                   # empty proposal
+    b[2] = 0                                                   # empty template
+    got = MT.mask_iou(a, b)
+    ref = M.mask_iou(list(a), list(b))
+    assert got.shape == (5, 3) and got.dtype == np.float64 and np.array_equal(got, ref)
+    assert got[4].sum() == 0 and got[:, 2].sum() == 0
+    inter, aa, ab = MT.mask_overlap(a * 255, b)               # nonzero = foreground
+    assert np.array_equal(aa.cpu().numpy(), a.reshape(5, -1).sum(1)) and np.array_equal(ab.cpu().numpy(), b.reshape(3, -1).sum(1))
+    assert np.array_equal(MT.mask_iou(a, a).diagonal()[:4], np.ones(4))
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (7, 5), (64, 33), (50, 4097)])
+def test_rle_encode_matches_host_encoder(h, w):
+    from premvos_amd import mergetrack as MT
+    m = _masks(h + w, 5, h, w, blobs=h > 8)
+    m[1] = 0
+    m[2] = 1
+    m[3] = np.random.default_rng(9).random((h, w)) > 0.5      # maximally ragged
+    segs = MT.encode_masks(m)
+    for i in range(5):
+        assert segs[i] == rle.encode(m[i]), i
+        assert np.array_equal(rle.decode(segs[i]), m[i])
+
+
+def test_warp_proposals_matches_oracle(tmp_path):
+    from premvos_amd import mergetrack as MT
+    from premvos_amd.flow.driver import writeFlowFile
+    m = _masks(11, 3, 48, 70)
+    f = _flow(4, 48, 70, 3.0)
+    props = [{"mask": m[i], "id": i + 1, "final_score": 0.1 * i, "object_score": 0.5 + 0.1 * i} for i in range(3)]
+    ref = M.warp_proposals(props, f, rle)
+    fn = str(tmp_path / "00000.flo")
+    writeFlowFile(fn, f)
+    for src in (fn, f, torch.from_numpy(f).cuda()):
+        got = MT.warp_proposals(props, src)
+        assert len(got) == 3
+        for a, b in zip(got, ref):
+            assert set(a) == set(b)
+            assert np.array_equal(a["mask"], b["mask"]) and a["mask"].dtype == np.uint8
+            assert a["segmentation"] == b["segmentation"] and a["bbox"] == b["bbox"]
+            assert (a["score"], a["final_score"], a["object_score"], a["id"]) == (b["score"], b["final_score"], b["object_score"], b["id"])
+    assert MT.warp_proposals([], f) == []
+
+
+def test_full_size_frame_properties():
+    """480x854, 20 masks: identity flow is the identity, IoU of a mask with itself is 1, RLE round-trips, and the
+    device results agree with the oracle on a sample of masks."""
+    from premvos_amd import mergetrack as MT
+    m = _masks(3, 20, 480, 854)
+    dm = torch.from_numpy(m).cuda()
+    z = torch.zeros((480, 854, 2), device="cuda")
+    assert torch.equal(MT.warp_masks(dm, z), dm)
+    f = _flow(8, 480, 854, 6.0)
+    w = MT.warp_masks(dm, f)
+    for i in (0, 7, 19):
+        assert np.array_equal(w[i].cpu().numpy(), M.warp_flow(m[i], f))
+    iou = MT.mask_iou(w, dm)
+    assert iou.shape == (20, 20) and np.array_equal(MT.mask_iou(dm, dm).diagonal(), np.ones(20))
+    assert np.array_equal(iou[:3, :2], M.mask_iou([x for x in w[:3].cpu().numpy()], list(m[:2])))
+    segs = MT.encode_masks(w)
+    wn = w.cpu().numpy()
+    for i in range(20):
+        assert np.array_equal(rle.decode(segs[i]), wn[i])
+    assert segs[5] == rle.encode(wn[5])
