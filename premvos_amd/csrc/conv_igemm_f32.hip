@@ -38,7 +38,10 @@ constexpr int BK = 16;           // k granularity of the packed weights (k_pad %
 // epilogue.  Used when a layer has too few output tiles to fill 256 CUs (coarse PWC levels, batch-1 RoI/feature maps).
 // KB: k depth of one LDS stage (16 or 32).  Rows are padded by 4 floats (KB+4): 20 and 36 dwords are both 4 x odd,
 // so 16 consecutive rows land on 16 different 16-byte bank slots -> conflict-free ds_read_b128.
-template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16>
+// PW: pointwise layers (1x1 taps, no padding; any stride): the gather address of an A row is a fixed pixel base + k, so
+// the per-stage tap bookkeeping and 64-bit address arithmetic of the general path drop out (most ResNet / Xception
+// layers; the scalar+vector work between the barrier and the first MFMA of a stage was ~15 % of a stage).
+template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16, bool PW = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -89,12 +92,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     rowbase[i] = p.in + (long)n * p.h * p.w * p.in_ps;
     iy0[i] = ok ? oy * p.sh - p.pt : -(1 << 28);  // invalid rows fail the bounds test below
     ix0[i] = ox * p.sw - p.pl;
+    if constexpr (PW) {                            // the one pixel this row reads (nullptr = row out of range)
+      rowbase[i] = ok ? rowbase[i] + ((long)(oy * p.sh) * p.w + ox * p.sw) * p.in_ps : nullptr;
+    }
   }
   const int KT_all = (p.k_pad + KB - 1) / KB;          // KB = 32 on a k_pad % 32 == 16 matrix: last half stage is zero
   const int kt_begin = SPLITK ? blockIdx.z * kt_per : 0;
   const int kt_end = SPLITK ? (kt_begin + kt_per < KT_all ? kt_begin + kt_per : KT_all) : KT_all;
-  int kh, kw, c;
-  {
+  int kh = 0, kw = 0, c;
+  if constexpr (PW) {
+    c = kt_begin * KB + j4;                        // k itself (single tap); k >= cin_pad is zero padding
+  } else {
     const int k0 = kt_begin * KB + j4;
     const int tap = k0 / p.cin_pad;
     c = k0 - tap * p.cin_pad;
@@ -112,23 +120,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
 
   float4 ra[A_PER_T], rb[B_PER_T];
   auto gload = [&](int kt) {
-    const bool tap_ok = kh < p.kh;
-    const int dy = kh * p.dh, dx = kw * p.dw;
+    if constexpr (PW) {
+      const bool kok = c < p.cin_pad;
 #pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-      const bool ok = tap_ok && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
-      ra[i] = ok ? *reinterpret_cast<const float4*>(rowbase[i] + ((long)iy * p.w + ix) * p.in_ps + c)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < A_PER_T; ++i)
+        ra[i] = (kok && rowbase[i] != nullptr) ? *reinterpret_cast<const float4*>(rowbase[i] + c)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const bool tap_ok = kh < p.kh;
+      const int dy = kh * p.dh, dx = kw * p.dw;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(rowbase[i] + ((long)iy * p.w + ix) * p.in_ps + c)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i)
       rb[i] = (wok[i] && kt * KB + j4 < p.k_pad) ? *reinterpret_cast<const float4*>(wrow[i] + kt * KB)
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
     c += KB;
-    while (c >= p.cin_pad) {
-      c -= p.cin_pad;
-      if (++kw == p.kw) { kw = 0; ++kh; }
+    if constexpr (!PW) {
+      while (c >= p.cin_pad) {
+        c -= p.cin_pad;
+        if (++kw == p.kw) { kw = 0; ++kh; }
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -339,8 +357,11 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>, LDS_BYTES);
+    allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB, true>, LDS_BYTES);
+    allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB, true>, LDS_BYTES);
     attr_done = true;
   }
+  const bool pw = d.kh == 1 && d.kw == 1 && d.pt == 0 && d.pl == 0;
   int splits = pick_splits(d, BM, BN, KB);
   const int KT = premvos::cdiv(d.k_pad, KB);
   if (splits > 1) {
@@ -350,7 +371,10 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     const long need = (long)splits * M * ncols * sizeof(float);
     if (splits > 1 && d.workspace != nullptr && (long)d.workspace_bytes >= need) {
       grid.z = splits;
-      hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per, 0);
+      if (pw)
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB, true>), grid, block, LDS_BYTES, s, d, kt_per, 0);
+      else
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per, 0);
       int rc = premvos::check_launch("conv_igemm_f32(split-k)");
       if (rc) return rc;
       return premvos::launch_splitk_reduce(d, splits, ncols, s, 0);
@@ -375,13 +399,19 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   const dim3 gmain(grid.x - tail, grid.y);
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>), gmain, block, LDS_BYTES, s, d, 0, 0);
+  else if (pw)
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB, true>), gmain, block, LDS_BYTES, s, d, 0, 0);
   else
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>), gmain, block, LDS_BYTES, s, d, 0, 0);
   int rc = premvos::check_launch("conv_igemm_f32");
   if (rc || !tail) return rc;
   const int mt0 = (int)grid.x - tail;
-  hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), dim3(tail, grid.y, tsplits), block, LDS_BYTES,
-                     s, d, tkt_per, mt0);
+  if (pw)
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB, true>), dim3(tail, grid.y, tsplits), block,
+                       LDS_BYTES, s, d, tkt_per, mt0);
+  else
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), dim3(tail, grid.y, tsplits), block,
+                       LDS_BYTES, s, d, tkt_per, mt0);
   rc = premvos::check_launch("conv_igemm_f32(tail split-k)");
   if (rc) return rc;
   return premvos::launch_splitk_reduce(d, tsplits, grid.y * BN, s, mt0 * BM);
