@@ -142,9 +142,20 @@ def roofline(pipe, batch):
         except Exception:
             traffic = None
     alg_bytes = sum(it[4] for it in items)
+    # what the fp32 MFMA pipe sustains on THIS GPU with nothing else going on (pure v_mfma_f32_32x32x2_f32 loop)
+    from premvos_amd import _lib
+    sink = torch.zeros(4, device="cuda")
+    lib, blocks, iters = _lib.load(), 1024, 20000
+    lib.premvos_mfma_f32_calibrate(1000, blocks, sink.data_ptr(), _lib.current_stream())
+    ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ca.record()
+    lib.premvos_mfma_f32_calibrate(iters, blocks, sink.data_ptr(), _lib.current_stream())
+    cb.record()
+    cb.synchronize()
+    ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(alg_bytes / nl),
+            "algorithmic_bytes_per_launch": round(alg_bytes / nl), "mfma_ceiling_measured": round(ceiling, 1),
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),
             "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
 

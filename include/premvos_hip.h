@@ -245,6 +245,11 @@ int premvos_refine_output_f32(const float* logits, int32_t logits_ps, int32_t lh
                               const int32_t* count, int32_t max_boxes, int32_t size, int32_t h, int32_t w,
                               uint8_t* mask, float* posterior, float* conf_score, void* workspace, void* stream);
 
+/* Calibration kernel: `blocks` workgroups of 4 waves each issue iters*16 independent v_mfma_f32_32x32x2_f32 per wave
+ * (FLOPs = blocks*4*iters*16*4096); timing it gives the fp32 MFMA rate the GPU sustains under its own power management
+ * (bench.py: roofline.mfma_ceiling_measured). */
+int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void* stream);
+
 /* Host-side utility (no GPU work): CRC-32C of a host buffer -- the checksum of TensorFlow tensor-bundle checkpoints,
  * which premvos_amd/weights.py reads and writes without TensorFlow (proposal_net/train.py:655, core/Saver.py:33-48). */
 uint32_t premvos_crc32c_host(const void* data, int64_t n);

@@ -40,7 +40,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-             "-Wno-unused-result"]
+             "-Wno-unused-result"] + os.environ.get("PREMVOS_EXTRA_HIPCC_FLAGS", "").split()      # dev experiments (-D...)
     procs, objs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

@@ -519,4 +519,38 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
 }
 
 extern "C" const char* premvos_last_error(void) { return premvos::g_err; }
+namespace {
+// Calibration: nothing but independent fp32 MFMAs (4 accumulators per wave, operands in registers) -- the issue-rate
+// ceiling of v_mfma_f32_32x32x2_f32 on this GPU under its own power/clock management.  bench.py reports it next to the
+// datasheet peak so that roofline.frac can be read against what the silicon sustains.
+__global__ __launch_bounds__(256) void mfma_f32_calibrate_kernel(long iters, float* sink) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = 1.0f + (float)threadIdx.x * 1e-6f, b = 1.0f - (float)threadIdx.x * 1e-6f;
+  for (long it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    a = -a;
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[i][r];
+  if (t == 123.456f) sink[0] = t;          // keeps the loop alive
+}
+}  // namespace
+
+extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void* stream) {
+  PV_REQUIRE(iters > 0 && blocks > 0 && sink != nullptr, "mfma_calibrate: bad arguments");
+  hipLaunchKernelGGL(mfma_f32_calibrate_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), (long)iters,
+                     sink);
+  return premvos::check_launch("mfma_f32_calibrate");
+}
+
 extern "C" int premvos_abi_version(void) { return 4; }

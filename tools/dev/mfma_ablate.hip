@@ -1,0 +1,107 @@
+// Dev experiment (standalone): what costs the conv kernel its last 20 % of MFMA issue rate?
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/abl tools/dev/mfma_ablate.hip && /tmp/abl
+// Variants of a 4-wave workgroup loop with the conv kernel's 128x128 / KB=16 structure:
+//   0 pure MFMA   1 + ds_read_b128 operands   2 + barrier per stage   3 + ds_write_b128 per stage   4 + global loads
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#ifndef WMAP
+#define WMAP 0
+#endif
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int KB = 16, RS = KB + 4, BM = 128, BN = 128;
+
+template <int V>
+__global__ __launch_bounds__(256) void k(long stages, const float* __restrict__ g, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  for (int i = tid; i < 2 * (BM + BN) * RS; i += 256) lds[i] = 1.0f + i * 1e-7f;
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  float4 ra[2], rb[2];
+  const float* gp = g + ((long)blockIdx.x * 256 + tid) * 4;
+  float4 af0[2], bf0[2];
+  af0[0] = af0[1] = bf0[0] = bf0[1] = make_float4(1.f, 1.0001f, 0.9999f, 1.f);
+  for (long s = 0; s < stages; ++s) {
+    const int buf = s & 1;
+    if (V >= 4) {
+      for (int i = 0; i < 2; ++i) {
+        ra[i] = *reinterpret_cast<const float4*>(gp + ((s * 4 + i) & 1023) * 262144L % (1 << 24));
+        rb[i] = *reinterpret_cast<const float4*>(gp + ((s * 4 + 2 + i) & 1023) * 262144L % (1 << 24));
+      }
+    } else {
+      ra[0] = ra[1] = rb[0] = rb[1] = af0[0];
+    }
+    const float* a = &lds[buf * (BM + BN) * RS + wm0 * RS + frag_off];
+    const float* b = &lds[buf * (BM + BN) * RS + (BM + wn0) * RS + frag_off];
+#pragma unroll
+    for (int h = 0; h < KB / 8; ++h) {
+      float4 af[2], bf[2];
+      if (V >= 1) {
+        for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+        for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+      } else {
+        af[0] = af0[0]; af[1] = af0[1]; bf[0] = bf0[0]; bf[1] = bf0[1];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (V >= 3) {
+      float* wa = &lds[(buf ^ 1) * (BM + BN) * RS];
+      for (int i = 0; i < 2; ++i) {
+#if WMAP == 1
+        // lanes of a 16-lane group hit rows g, g+4, g+8, g+12: (5*row + chunk) mod 16 all distinct
+        const int row = (wave * 16 + ((lane >> 2) & 3) * 4 + (lane >> 4)) + i * 64;
+#elif WMAP == 2
+        // 8-lane groups -> rows g, g+8
+        const int row = (wave * 16 + ((lane >> 2) & 1) * 8 + (lane >> 3)) + i * 64;
+#else
+        const int row = (tid >> 2) + i * 64;
+#endif
+        *reinterpret_cast<float4*>(wa + row * RS + (tid & 3) * 4) = ra[i];
+        *reinterpret_cast<float4*>(wa + (BM + row) * RS + (tid & 3) * 4) = rb[i];
+      }
+    }
+    if (V >= 2) __syncthreads();
+  }
+  float t = 0.f;
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+  if (t == 123.456f) sink[0] = t;
+}
+
+template <int V>
+void run(int blocks, long stages, const float* g, float* sink, int lds_bytes) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k<V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), lds_bytes, 0, stages / 8, g, sink);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), lds_bytes, 0, stages, g, sink);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double fl = (double)blocks * 4 * stages * 32 * 4096.0;
+  printf("variant %d  blocks %4d  lds %6d B: %7.1f TF/s  (%.2f ms)  %s\n", V, blocks, lds_bytes, fl / (ms * 1e-3) / 1e12, ms,
+         hipGetErrorString(hipGetLastError()));
+}
+
+int main(int argc, char** argv) {
+  float *g, *sink;
+  hipMalloc(&g, (1L << 25) * 4); hipMemset(g, 0, (1L << 25) * 4); hipMalloc(&sink, 64);
+  const long stages = 4000;
+  const int lds = 2 * (BM + BN) * RS * 4;           // 40960 B -> 3-4 workgroups per CU
+  printf("WMAP %d\n", WMAP);
+  for (int blocks : {768}) {
+    run<2>(blocks, stages, g, sink, lds); run<3>(blocks, stages, g, sink, lds); run<4>(blocks, stages, g, sink, lds);
+  }
+  return 0;
+}
