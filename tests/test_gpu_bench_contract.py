@@ -1,0 +1,40 @@
+"""bench.py's driver contract, exercised end to end on one GPU: ONE JSON line with the contract's keys, and the
+multi-GPU code path (process group over RCCL, per-step gather to the merge rank, max-over-ranks timing) with world
+size 1 (PREMVOS_BENCH_FORCE_DIST=1) -- the 8-GPU launch itself is the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_through_the_distributed_path():
+    d = _run({"PREMVOS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
+              "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+             "--no-cpu-baseline")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]          # frames / time, whole job
+    assert d["value"] > 10.0                                                               # an MI355X does > 10 frames/s
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 20 < r["achieved"] < r["mfma_ceiling_measured"] <= 160
+    assert "workload" in d["config"] and "model" not in d["config"]
