@@ -255,6 +255,22 @@ int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void*
 uint32_t premvos_crc32c_host(const void* data, int64_t n);
 
 /* ------------------------------------------------------------------------------------------
+ * ReID embedding net (code/ReID_net).  Its convs / FC layers go through premvos_conv2d_f32, the pool
+ * through premvos_maxpool_f32.
+ * ---------------------------------------------------------------------------------------- */
+/* datasets/Similarity/DAVIS_Forward_Feed.py:62-96 (zero_small = 1: boxes with min(w,h) <= 10 give a zero image) and
+ * Similarity.py:288-297 (zero_small = 0): frame uint8 RGB [h][w][3] / 255, crop boxes_xywh[i] (int32 x, y, w, h; already
+ * context-expanded, rounded and clipped by the host), tf.image.resize_images bilinear (TF1 legacy) to size x size,
+ * (x - mean) / std -> NHWC [n][size][size][4] (4th channel 0). */
+int premvos_reid_input_u8(const uint8_t* frame_rgb, int32_t h, int32_t w, const int32_t* boxes_xywh, int32_t n,
+                          int32_t size, int32_t zero_small, float* out, void* stream);
+
+/* Inference BatchNorm (+ ReLU when relu != 0) as a per-channel scale / shift over NHWC pixels, for pre-activation units
+ * whose input is also consumed raw by the identity shortcut (network/NetworkLayers.py:171-173). */
+int premvos_scale_shift_relu_f32(const float* in, int32_t in_ps, int64_t npix, int32_t c, const float* scale,
+                                 const float* shift, float* out, int32_t out_ps, int32_t relu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * MergeTrack-side mask helpers (the consumer of the hot path).  Masks are uint8 [n][h][w] row-major,
  * nonzero = foreground, resident in HBM.
  * ---------------------------------------------------------------------------------------- */

@@ -65,6 +65,8 @@ SIGNATURES = {
     "premvos_broadcast_pixel_f32": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "premvos_refine_output_f32": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "premvos_mfma_f32_calibrate": [C.c_int64, _i32, _vp, _vp],
+    "premvos_reid_input_u8": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
+    "premvos_scale_shift_relu_f32": [_vp, _i32, C.c_int64, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "premvos_mask_warp_u8": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "premvos_mask_overlap_u8": [_vp, _i32, _vp, _i32, C.c_int64, _vp, _vp, _vp, _vp],
     "premvos_rle_boundaries_u8": [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp],

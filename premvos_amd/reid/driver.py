@@ -1,0 +1,117 @@
+"""ReID stage driver: the counterpart of ``ReID_net/main.py configs/run`` (batch stage) and of the in-process API
+MergeTrack uses (MergeTrack/ReID_net_functions.py:19-45).
+
+Reference boundary kept:
+  * batch stage (datasets/Similarity/DAVIS_Forward_Similarity.py:25-43 + Forwarding/ReIDForwarding.py:34-92): every
+    <bb_input_dir>/<seq>/<frame>.json is copied to <output_dir>/<seq>/<frame>.json with "ReID": [128 floats] added to
+    each proposal whose ``toBbox(segmentation)`` has w > 0 and h > 0 (the others stay without the key);
+  * in-process: ``engine = ReID_net_init()``; ``add_ReID(proposals, image_fn, engine)`` -> every proposal's 'bbox' (xywh)
+    gets its embedding (crops of the in-merge feed dataset: excess >= 1 pixel, zero image for boxes <= 10 px).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import sys
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import rle
+from ..refinement.driver import Config as _TypedConfig
+from .model import ReIDNet
+
+BATCH = 40
+
+
+class Config(_TypedConfig):
+    """ReID_net/Config.py spells the string getter ``str`` (configs are read with ``config.str("model")``)."""
+
+    def str(self, key, default=None):
+        return self.string(key, default)
+
+
+def load_weights(path: str) -> Dict[str, object]:
+    from ..weights import load_any
+    return load_any(path, "reid")
+
+
+class ReIDEngine:
+    def __init__(self, net: ReIDNet, max_boxes: int = BATCH):
+        self.net, self.max_boxes = net, max_boxes
+
+    def embed(self, image_rgb: np.ndarray, boxes_xywh, feed: bool) -> np.ndarray:
+        boxes = np.asarray(boxes_xywh, np.float32).reshape(-1, 4)
+        out = np.zeros((len(boxes), 128), np.float32)
+        frame = torch.from_numpy(np.array(image_rgb[:, :, :3], dtype=np.uint8, order="C")).to(self.net.device)
+        for s in range(0, len(boxes), self.max_boxes):
+            chunk = boxes[s:s + self.max_boxes]
+            P = self.max_boxes if len(boxes) > self.max_boxes else _bucket(len(chunk))
+            out[s:s + len(chunk)] = self.net.embed(frame, chunk, max_boxes=P, feed=feed).cpu().numpy()
+        return out
+
+
+def _bucket(n: int) -> int:
+    for b in (1, 2, 4, 8, 12, 20, 40):
+        if n <= b:
+            return b
+    return n
+
+
+def ReID_net_init(config_path: str = "ReID_net/configs/live") -> ReIDEngine:
+    cfg = Config(config_path)
+    return ReIDEngine(ReIDNet(load_weights(cfg.str("load"))))
+
+
+def add_ReID(proposals: List[dict], image_fn: str, ReID_net: ReIDEngine) -> List[dict]:
+    """MergeTrack/ReID_net_functions.py:26-45."""
+    from PIL import Image
+    if not proposals:
+        return proposals
+    image = np.asarray(Image.open(image_fn).convert("RGB"))
+    emb = ReID_net.embed(image, [p["bbox"] for p in proposals], feed=True)
+    for p, e in zip(proposals, emb):
+        p["ReID"] = e.tolist()
+    return proposals
+
+
+def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: str, output_dir: str) -> int:
+    from PIL import Image
+    n = 0
+    for jf in sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json"))):
+        rel = os.path.relpath(jf, bb_input_dir)
+        with open(jf) as f:
+            proposals = json.load(f)
+        boxes, idx = [], []
+        for i, p in enumerate(proposals):
+            bb = rle.to_bbox(p["segmentation"])
+            if bb[2] <= 0 or bb[3] <= 0:
+                continue
+            boxes.append(bb)
+            idx.append(i)
+        if boxes:
+            image = np.asarray(Image.open(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")).convert("RGB"))
+            emb = engine.embed(image, boxes, feed=False)
+            for i, e in zip(idx, emb):
+                proposals[i]["ReID"] = np.array(e).tolist()
+        out_fn = os.path.join(output_dir, rel)
+        os.makedirs(os.path.dirname(out_fn), exist_ok=True)
+        with open(out_fn, "w") as f:
+            json.dump(proposals, f)
+        n += 1
+    return n
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    argv = sys.argv[1:] if argv is None else argv
+    assert len(argv) == 1, "usage: driver.py <config>"
+    cfg = Config(argv[0])
+    engine = ReIDEngine(ReIDNet(load_weights(cfg.str("load"))))
+    forward_directory(engine, cfg.dir("image_input_dir"), cfg.dir("bb_input_dir"), cfg.dir("output_dir"))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

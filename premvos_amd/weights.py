@@ -398,10 +398,44 @@ def refinement_weights_to_tf(w: Dict[str, object]) -> Dict[str, np.ndarray]:
     return v
 
 
+def reid_weights_from_tf(v: Dict[str, np.ndarray]) -> Dict[str, object]:
+    """ReID_net variable names (network/NetworkLayers.py:62-76 'W' / 'b'; Util_Network.py:87-97
+    '<scope>/{beta,gamma,mean_ema,var_ema}') -> the dict ``ReIDNet`` takes: conv W HWIO -> OIHW, FC W [in,out] -> [out,in]."""
+    w: Dict[str, object] = {}
+    for name, a in v.items():
+        if name.endswith("/gamma"):
+            p = name[:-len("/gamma")]
+            w[p] = {"gamma": _t(v[p + "/gamma"]), "beta": _t(v[p + "/beta"]), "mean": _t(v[p + "/mean_ema"]),
+                    "var": _t(v[p + "/var_ema"])}
+        elif name.rsplit("/", 1)[-1][:1] == "W" and a.ndim == 4:
+            w[name] = _t(a.transpose(3, 2, 0, 1))
+        elif name.endswith("/W") and a.ndim == 2:
+            w[name] = _t(a.T)
+        elif name.endswith("/b"):
+            w[name] = _t(a)
+    return w
+
+
+def reid_weights_to_tf(w: Dict[str, object]) -> Dict[str, np.ndarray]:
+    v: Dict[str, np.ndarray] = {}
+    for key, a in w.items():
+        if isinstance(a, dict):
+            v[key + "/gamma"], v[key + "/beta"] = a["gamma"].numpy(), a["beta"].numpy()
+            v[key + "/mean_ema"], v[key + "/var_ema"] = a["mean"].numpy(), a["var"].numpy()
+        elif a.dim() == 4:
+            v[key] = np.ascontiguousarray(a.numpy().transpose(2, 3, 1, 0))
+        elif a.dim() == 2:
+            v[key] = np.ascontiguousarray(a.numpy().T)
+        else:
+            v[key] = a.numpy()
+    return v
+
+
 def load_any(path: str, kind: str) -> Dict[str, object]:
     """``path`` = a torch pickle of the name->tensor dict, or a TF checkpoint prefix (what simple_run.sh passes)."""
     if os.path.exists(path + ".index"):
         v = load_tf_checkpoint(path)
-        return proposal_weights_from_tf(v) if kind == "proposal" else refinement_weights_from_tf(v)
+        return {"proposal": proposal_weights_from_tf, "refinement": refinement_weights_from_tf,
+                "reid": reid_weights_from_tf}[kind](v)
     import torch
     return torch.load(path, map_location="cpu")
