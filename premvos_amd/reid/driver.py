@@ -33,6 +33,35 @@ class Config(_TypedConfig):
         return self.string(key, default)
 
 
+def units_from_config(network: Dict[str, dict]):
+    """The ``"network"`` table of the config (configs/run:37-70) -> the (name, n_features, filter sizes, strides) list
+    ``ReIDNet`` takes, with ResidualUnit2's defaults (NetworkLayers.py:148-166): 2 convs, 3x3 filters, stride 1,
+    n_features = the input's.  Only the layer classes of the shipped ReID net are accepted."""
+    units, feats_in = [], None
+    order = []
+    for name, spec in network.items():
+        cls = spec["class"]
+        if cls == "Conv" and "from" not in spec:
+            assert spec.get("activation") == "linear" and not spec.get("batch_norm", False), "unsupported stem"
+            feats_in = spec["n_features"]
+        elif cls == "ResidualUnit2":
+            assert feats_in is not None and spec["from"] == [order[-1]], "the ReID net is a plain chain"
+            n = spec.get("n_convs", 2)
+            f = spec.get("n_features", feats_in)
+            f = list(f) if isinstance(f, list) else [f] * n
+            ks = [k[0] for k in spec.get("filter_size", [[3, 3]] * n)]
+            st = [s[0] for s in spec.get("strides", [[1, 1]] * n)]
+            assert len(f) == len(ks) == len(st) == n and "dilations" not in spec
+            units.append((name, tuple(f), tuple(ks), tuple(st)))
+            feats_in = f[-1]
+        elif cls in ("Conv", "FullyConnected", "FullyConnectedWithTripletLoss"):
+            pass                                   # conv1 / fc1 / fc2 / outputTriplet: shapes come from the weights
+        else:
+            raise ValueError(f"unsupported layer class {cls!r} in the ReID network table")
+        order.append(name)
+    return units
+
+
 def load_weights(path: str) -> Dict[str, object]:
     from ..weights import load_any
     return load_any(path, "reid")
@@ -60,9 +89,13 @@ def _bucket(n: int) -> int:
     return n
 
 
+def engine_from_config(cfg: "Config") -> ReIDEngine:
+    units = units_from_config(cfg.dict("network")) if cfg.has("network") else None
+    return ReIDEngine(ReIDNet(load_weights(cfg.str("load")), **({"units": units} if units else {})))
+
+
 def ReID_net_init(config_path: str = "ReID_net/configs/live") -> ReIDEngine:
-    cfg = Config(config_path)
-    return ReIDEngine(ReIDNet(load_weights(cfg.str("load"))))
+    return engine_from_config(Config(config_path))
 
 
 def add_ReID(proposals: List[dict], image_fn: str, ReID_net: ReIDEngine) -> List[dict]:
@@ -108,7 +141,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     argv = sys.argv[1:] if argv is None else argv
     assert len(argv) == 1, "usage: driver.py <config>"
     cfg = Config(argv[0])
-    engine = ReIDEngine(ReIDNet(load_weights(cfg.str("load"))))
+    engine = engine_from_config(cfg)
     forward_directory(engine, cfg.dir("image_input_dir"), cfg.dir("bb_input_dir"), cfg.dir("output_dir"))
     return 0
 

@@ -24,6 +24,9 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--general_weights", default="weights/PReMVOS_weights/proposal_net/general_weights/proposal_general_weights")
     ap.add_argument("--specific_weights", default="weights/PReMVOS_weights/proposal_net/specific_weights/proposal_specific_weights")
     ap.add_argument("--refinement_weights", default="weights/PReMVOS_weights/refinement_net/specific_weights/refinement_specific_weights")
+    ap.add_argument("--reid_config", default="code/ReID_net/configs/run",
+                    help="ReID config (network table + 'load'); its relative paths are taken from the config's grandparent "
+                         "directory, like the reference which runs the stage from code/")
     a = ap.parse_args(argv)
     os.chdir(a.root)
     inter = "output/intermediate"
@@ -53,6 +56,16 @@ def main(argv: Optional[List[str]] = None) -> int:
         eng = rd.RefinementEngine(rd.RefinementNet(w, rd.infer_num_middle(w)))
         rd.forward_directory(eng, "data/DAVIS/JPEGImages/480p/", comb + "/", refined + "/")
         done.append("refined_proposals")
+    reid = f"{inter}/ReID_proposals"
+    if not os.path.isdir(reid) and os.path.exists(a.reid_config):     # :60-68
+        from premvos_amd.reid import driver as qd
+        cfg = qd.Config(a.reid_config)
+        base = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(a.reid_config))))     # .../code
+        if not os.path.isabs(cfg.str("load")):
+            cfg._entries["load"] = os.path.normpath(os.path.join(base, cfg.str("load")))
+        eng = qd.engine_from_config(cfg)
+        qd.forward_directory(eng, "data/DAVIS/JPEGImages/480p/", refined + "/", reid + "/")
+        done.append("ReID_proposals")
     print("stages run:", done)
     return 0
 

@@ -13,8 +13,21 @@ pytestmark = pytest.mark.gpu
 from oracle import proposal_oracle as PO  # noqa: E402
 from oracle import pwc_oracle as O  # noqa: E402
 from oracle import refinement_oracle as RO  # noqa: E402
+from oracle import reid_oracle as QO  # noqa: E402
 
 BLOCKS, MIDDLE = (1, 1, 2, 1), 1
+REID_UNITS = [QO.UNITS[0], ("res3", 2, (64, 64), (3, 3), (2, 1)), ("res15", 3, (32, 64, 96), (1, 3, 1), (1, 2, 1))]
+REID_NETWORK = {"conv0": {"class": "Conv", "n_features": 64, "activation": "linear"},
+                "res0": {"class": "ResidualUnit2", "n_features": 128, "strides": [[2, 2], [1, 1]], "from": ["conv0"]},
+                "res3": {"class": "ResidualUnit2", "n_features": 64, "strides": [[2, 2], [1, 1]], "from": ["res0"]},
+                "res15": {"class": "ResidualUnit2", "n_convs": 3, "n_features": [32, 64, 96],
+                          "filter_size": [[1, 1], [3, 3], [1, 1]], "strides": [[1, 1], [2, 2], [1, 1]], "from": ["res3"]},
+                "conv1": {"class": "Conv", "n_features": 500, "batch_norm": True, "filter_size": [3, 3], "pool_size": [3, 3],
+                          "from": ["res15"]},
+                "fc1": {"class": "FullyConnected", "n_features": 500, "batch_norm": True, "from": ["conv1"]},
+                "fc2": {"class": "FullyConnected", "n_features": 500, "batch_norm": True, "from": ["fc1"]},
+                "outputTriplet": {"class": "FullyConnectedWithTripletLoss", "n_features": 128, "batch_norm": True,
+                                  "activation": "linear", "from": ["fc2"]}}
 
 
 def _make_tree(root, h=120, w=200, t=3):
@@ -36,6 +49,12 @@ def _make_tree(root, h=120, w=200, t=3):
     W.save_tf_checkpoint(str(wd / "proposal_general_weights"), W.proposal_weights_to_tf(PO.synth_weights(0, BLOCKS)))
     torch.save(PO.synth_weights(1, BLOCKS), wd / "specific.pt")
     W.save_tf_checkpoint(str(wd / "refinement_specific_weights"), W.refinement_weights_to_tf(RO.synth_weights(0, MIDDLE)))
+    # ReID: config under code/ReID_net/configs/ with a relative 'load' (the reference runs that stage from code/)
+    W.save_tf_checkpoint(str(wd / "ReID_general_weights"), W.reid_weights_to_tf(QO.synth_weights(0, REID_UNITS)))
+    cdir = root / "code" / "ReID_net" / "configs"
+    cdir.mkdir(parents=True)
+    (cdir / "run").write_text("# reduced ReID net for the plumbing test\n" + json.dumps(
+        {"model": "Re-ID", "load": "../weights/ReID_general_weights", "input_size": [128, 128], "network": REID_NETWORK}))
     return frames
 
 
@@ -84,6 +103,24 @@ def test_three_frame_clip_end_to_end(tmp_path):
         for a, b in zip(r0[:3], ref0):
             assert abs(float(a["conf_score"]) - float(b["conf_score"])) < 2e-3
             assert (rle.decode(a["segmentation"]) != RO.rle_decode(b["segmentation"])).mean() < 5e-3
+        # ReID stage: every refined proposal with a non-empty mask gains a 128-d embedding (ReIDForwarding.py:68-74)
+        for t in range(3):
+            r = json.load(open(inter / "refined_proposals" / "bear" / f"{t:05d}.json"))
+            q = json.load(open(inter / "ReID_proposals" / "bear" / f"{t:05d}.json"))
+            assert len(q) == len(r)
+            for a, b in zip(q, r):
+                assert {k: v for k, v in a.items() if k != "ReID"} == b
+                bb = rle.to_bbox(b["segmentation"])
+                assert ("ReID" in a) == (bb[2] > 0 and bb[3] > 0)
+                assert "ReID" not in a or (len(a["ReID"]) == 128 and np.isfinite(a["ReID"]).all())
+        q0 = json.load(open(inter / "ReID_proposals" / "bear" / "00000.json"))
+        have = [p for p in q0 if "ReID" in p][:2]
+        if have:
+            cb = QO.context_boxes([rle.to_bbox(p["segmentation"]) for p in have], 120, 200, feed=False)
+            ref = QO.forward(QO.synth_weights(0, REID_UNITS), np.stack([QO.make_crop(frames[0], b, feed=False) for b in cb]),
+                             REID_UNITS)
+            for p, e in zip(have, ref):
+                assert np.abs(np.array(p["ReID"]) - e).max() < 1e-3 * max(1.0, np.abs(ref).max())
         # stage-level resume: nothing is recomputed when the directories exist (simple_run.sh:23,30,38,46,53)
         before = {p: os.path.getmtime(p) for p in map(str, inter.rglob("*")) if os.path.isfile(p)}
         assert run_pipeline.main(args) == 0
