@@ -66,6 +66,19 @@ def main(argv: Optional[List[str]] = None) -> int:
         eng = qd.engine_from_config(cfg)
         qd.forward_directory(eng, "data/DAVIS/JPEGImages/480p/", refined + "/", reid + "/")
         done.append("ReID_proposals")
+    final = "output/final"
+    if not os.path.isdir(final) and os.path.isdir(reid) and os.path.exists(a.reid_config):       # :70-77
+        from premvos_amd import mergetrack
+        from premvos_amd.refinement import driver as rd
+        from premvos_amd.reid import driver as qd
+        w = rd.load_weights(a.refinement_weights)
+        r_eng = rd.RefinementEngine(rd.RefinementNet(w, rd.infer_num_middle(w)))
+        cfg = qd.Config(a.reid_config)
+        base = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(a.reid_config))))
+        if not os.path.isabs(cfg.str("load")):
+            cfg._entries["load"] = os.path.normpath(os.path.join(base, cfg.str("load")))
+        mergetrack.merge_all(r_eng, qd.engine_from_config(cfg))
+        done.append("final")
     print("stages run:", done)
     return 0
 

@@ -41,6 +41,14 @@ def _make_tree(root, h=120, w=200, t=3):
         Image.fromarray(img).save(seq_dir / f"{i:05d}.jpg", quality=95)
         frames.append(np.asarray(Image.open(seq_dir / f"{i:05d}.jpg").convert("RGB")))
     (root / "seq_to_run.txt").write_text("data/DAVIS/JPEGImages/480p/bear/\n")
+    # first-frame annotation: two objects, ids 1 and 2, as a palette PNG (MergeTrack reads it with PIL)
+    ann = np.zeros((h, w), np.uint8)
+    ann[30:80, 40:100] = 1
+    ann[50:110, 120:180] = 2
+    adir = root / "data" / "DAVIS" / "Annotations" / "480p" / "bear"
+    adir.mkdir(parents=True)
+    from premvos_amd.mergetrack import save_with_pascal_colormap
+    save_with_pascal_colormap(str(adir / "00000.png"), ann)
     wd = root / "weights"
     wd.mkdir()
     torch.save({"state_dict": O.synth_state_dict(0)}, wd / "pwc.pth.tar")
@@ -121,6 +129,18 @@ def test_three_frame_clip_end_to_end(tmp_path):
                              REID_UNITS)
             for p, e in zip(have, ref):
                 assert np.abs(np.array(p["ReID"]) - e).max() < 1e-3 * max(1.0, np.abs(ref).max())
+        # merge stage: one palette PNG per frame; frame 0 reproduces its annotation (IoU 1, ReID distance 0 with itself),
+        # later frames carry the same ids
+        from PIL import Image
+        from premvos_amd.mergetrack import pascal_colormap
+        ann = np.array(Image.open(tmp_path / "data" / "DAVIS" / "Annotations" / "480p" / "bear" / "00000.png"))
+        for t in range(3):
+            im = Image.open(tmp_path / "output" / "final" / "bear" / f"{t:05d}.png")
+            assert im.mode == "P" and np.array_equal(np.array(im.getpalette()[:768]).reshape(256, 3), pascal_colormap())
+            lab = np.array(im)
+            assert lab.shape == (120, 200) and set(np.unique(lab)) <= {0, 1, 2}
+            if t == 0:
+                assert np.array_equal(lab, ann)
         # stage-level resume: nothing is recomputed when the directories exist (simple_run.sh:23,30,38,46,53)
         before = {p: os.path.getmtime(p) for p in map(str, inter.rglob("*")) if os.path.isfile(p)}
         assert run_pipeline.main(args) == 0

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k(long stages, const float* __restrict__ 
   af0[0] = af0[1] = bf0[0] = bf0[1] = make_float4(1.f, 1.0001f, 0.9999f, 1.f);
   for (long s = 0; s < stages; ++s) {
     const int buf = s & 1;
-    if (V >= 4) {
+    if (V == 4) {
       for (int i = 0; i < 2; ++i) {
         ra[i] = *reinterpret_cast<const float4*>(gp + ((s * 4 + i) & 1023) * 262144L % (1 << 24));
         rb[i] = *reinterpret_cast<const float4*>(gp + ((s * 4 + 2 + i) & 1023) * 262144L % (1 << 24));
@@ -37,10 +37,29 @@ __global__ __launch_bounds__(256) void k(long stages, const float* __restrict__ 
     }
     const float* a = &lds[buf * (BM + BN) * RS + wm0 * RS + frag_off];
     const float* b = &lds[buf * (BM + BN) * RS + (BM + wn0) * RS + frag_off];
+    if (V == 5) {   // direct global -> LDS (no VGPR staging, no ds_write): rows unpadded (KB floats), chunk slot XOR-swizzled
+      float* dst = &lds[(buf ^ 1) * (BM + BN) * KB];
+      for (int i = 0; i < 2; ++i) {
+        const float* src = gp + ((s * 4 + i) & 1023) * 262144L % (1 << 24);
+        __builtin_amdgcn_global_load_lds(src, dst + (i * 256 + wave * 64) * 4, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src + 64, dst + BM * KB + (i * 256 + wave * 64) * 4, 16, 0, 0);
+      }
+    }
 #pragma unroll
     for (int h = 0; h < KB / 8; ++h) {
       float4 af[2], bf[2];
-      if (V >= 1) {
+      if (V == 5) {
+        const int r = lane & 31, q = 2 * h + (lane >> 5);
+        const float* base = &lds[buf * (BM + BN) * KB];
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = wm0 + mi * 32 + r;
+          af[mi] = *reinterpret_cast<const float4*>(base + (row * 4 + (q ^ ((row >> 2) & 3))) * 4);
+        }
+        for (int ni = 0; ni < 2; ++ni) {
+          const int row = wn0 + ni * 32 + r;
+          bf[ni] = *reinterpret_cast<const float4*>(base + BM * KB + (row * 4 + (q ^ ((row >> 2) & 3))) * 4);
+        }
+      } else if (V >= 1) {
         for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
         for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
       } else {
@@ -56,7 +75,8 @@ __global__ __launch_bounds__(256) void k(long stages, const float* __restrict__ 
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
         }
     }
-    if (V >= 3) {
+    if (V == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (V >= 3 && V != 5) {
       float* wa = &lds[(buf ^ 1) * (BM + BN) * RS];
       for (int i = 0; i < 2; ++i) {
 #if WMAP == 1
@@ -102,6 +122,9 @@ int main(int argc, char** argv) {
   printf("WMAP %d\n", WMAP);
   for (int blocks : {768}) {
     run<2>(blocks, stages, g, sink, lds); run<3>(blocks, stages, g, sink, lds); run<4>(blocks, stages, g, sink, lds);
+    run<5>(blocks, stages, g, sink, 2 * (BM + BN) * KB * 4);
+    run<5>(1024, stages, g, sink, 2 * (BM + BN) * KB * 4);
+    run<4>(1024, stages, g, sink, lds);
   }
   return 0;
 }
