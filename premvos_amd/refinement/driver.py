@@ -211,7 +211,7 @@ class RefinementEngine:
         if not proposals:
             return proposals
         boxes = _boxes_from_proposals(proposals)
-        frame = torch.from_numpy(np.ascontiguousarray(image_rgb[:, :, :3])).to(self.net.device)
+        frame = torch.from_numpy(np.array(image_rgb[:, :, :3], dtype=np.uint8, order="C")).to(self.net.device)
         for s in range(0, len(proposals), self.max_boxes):
             chunk = boxes[s:s + self.max_boxes]
             P = self.max_boxes if len(proposals) > self.max_boxes else _bucket(len(chunk))
