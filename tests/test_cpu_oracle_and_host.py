@@ -163,6 +163,17 @@ def test_product_path_refuses_to_run_without_gpu():
         net.load_state_dict(O.synth_state_dict(0))
     with pytest.raises(_lib.PremvosError):
         net(torch.zeros((1, 6, 64, 64)))
+    # every other entry of the product path: no CPU fallback anywhere
+    from premvos_amd import mergetrack
+    from premvos_amd.proposal import ProposalNet
+    from premvos_amd.refinement import RefinementNet
+    from premvos_amd.reid import ReIDNet
+    for ctor in (lambda: ProposalNet({}, (1, 1, 1, 1)), lambda: RefinementNet({}, 1), lambda: ReIDNet({}),
+                 lambda: mergetrack.warp_masks(np.zeros((1, 4, 4), np.uint8), np.zeros((4, 4, 2), np.float32)),
+                 lambda: mergetrack.mask_iou(np.zeros((1, 4, 4), np.uint8), np.zeros((1, 4, 4), np.uint8)),
+                 lambda: mergetrack.encode_masks(np.zeros((1, 4, 4), np.uint8))):
+        with pytest.raises(_lib.PremvosError):
+            ctor()
 
 
 def test_product_path_never_imports_the_oracle():
