@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("PREMVOS_BENCH_PRECISION", "fp32"),
                     choices=["fp32", "bf16x3", "bf16", "mixed-bf16x3", "mixed-bf16"],
                     help="MFMA arithmetic of the dense convs; mixed-*: PWC-Net fp32, proposal/refinement in the bf16 mode")
+    ap.add_argument("--frame", default="480p", choices=["480p", "1080p"],
+                    help="480p = the metric's DAVIS shape (default); 1080p = configs[4]'s 1080x1920 frames (supplementary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -162,6 +164,10 @@ def roofline(pipe, batch):
 
 def main():
     a = parse()
+    global H, W
+    if a.frame == "1080p":
+        H, W = 1080, 1920
+        a.no_cpu_baseline = True            # the CPU sample is defined on the metric's 480p workload
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -238,12 +244,15 @@ def main():
                   "mixed-bf16x3": "flow f32; proposal+refinement bf16x3 (split-fp32, f32 accumulate)",
                   "mixed-bf16": "flow f32; proposal+refinement bf16 (f32 accumulate)"}[prec],
         "data": "synthetic",
-        "config": {"workload": "configs[3] on one node: full per-frame pipe on synthetic DAVIS-shape 480x854 uint8 frames in "
-                               "HBM: PWC-Net flow (512x896) + proposal_net x2 weight sets (749x1333, ResNet-101-C4, 100 RoIs) "
-                               f"+ refinement_net (Xception-65 DeepLabv3+, {P_BOXES} seeded boxes/frame @385x385); conv arithmetic: {prec}; "
-                               "results (flow, masks, conf, boxes) left in HBM",
+        "config": {"workload": ("configs[3] on one node: full per-frame pipe on synthetic DAVIS-shape 480x854 uint8 frames in "
+                                "HBM: PWC-Net flow (512x896) + proposal_net x2 weight sets (749x1333, ResNet-101-C4, 100 RoIs) "
+                                if a.frame == "480p" else
+                                "configs[4] shape on one node (supplementary, fp32): synthetic 1080x1920 uint8 frames in HBM: "
+                                "PWC-Net flow (1088x1920) + proposal_net x2 weight sets (750x1333, ResNet-101-C4, 100 RoIs) ")
+                               + f"+ refinement_net (Xception-65 DeepLabv3+, {P_BOXES} seeded boxes/frame @385x385); conv arithmetic: {prec}; "
+                               + "results (flow, masks, conf, boxes) left in HBM",
                    "frames_per_step_per_gpu": B, "stages": ["flow", "proposal_general", "proposal_specific", "refinement"],
-                   "gflop_per_frame": 2420,
+                   "gflop_per_frame": 2420 if a.frame == "480p" else 3018,
                    "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of results to rank 0 per step"},
     }
     if rank == 0:
