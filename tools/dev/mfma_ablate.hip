@@ -25,8 +25,20 @@ __global__ __launch_bounds__(256) void k(long stages, const float* __restrict__ 
   const float* gp = g + ((long)blockIdx.x * 256 + tid) * 4;
   float4 af0[2], bf0[2];
   af0[0] = af0[1] = bf0[0] = bf0[1] = make_float4(1.f, 1.0001f, 0.9999f, 1.f);
+  float4 bnext[2][2];
+  if (V == 6) {
+    for (int h = 0; h < 2; ++h) for (int ni = 0; ni < 2; ++ni)
+      bnext[h][ni] = *reinterpret_cast<const float4*>(g + ((long)blockIdx.x * 4096 + (wave & 1) * 1024 + (h * 2 + ni) * 256 + lane * 4) % (1 << 24));
+  }
   for (long s = 0; s < stages; ++s) {
     const int buf = s & 1;
+    float4 bcur[2][2];
+    if (V == 6) {
+      for (int h = 0; h < 2; ++h) for (int ni = 0; ni < 2; ++ni) bcur[h][ni] = bnext[h][ni];
+      for (int h = 0; h < 2; ++h) for (int ni = 0; ni < 2; ++ni)      // next stage's B fragments: 4 contiguous 1 KB wave loads
+        bnext[h][ni] = *reinterpret_cast<const float4*>(g + (((s + 1) * 65536 + (long)blockIdx.x * 4096 + (wave & 1) * 1024 + (h * 2 + ni) * 256 + lane * 4) % (1 << 24)));
+      for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const float4*>(gp + ((s * 4 + i) & 1023) * 262144L % (1 << 24));
+    }
     if (V == 4) {
       for (int i = 0; i < 2; ++i) {
         ra[i] = *reinterpret_cast<const float4*>(gp + ((s * 4 + i) & 1023) * 262144L % (1 << 24));
@@ -59,6 +71,9 @@ __global__ __launch_bounds__(256) void k(long stages, const float* __restrict__ 
           const int row = wn0 + ni * 32 + r;
           bf[ni] = *reinterpret_cast<const float4*>(base + BM * KB + (row * 4 + (q ^ ((row >> 2) & 3))) * 4);
         }
+      } else if (V == 6) {
+        for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+        for (int ni = 0; ni < 2; ++ni) bf[ni] = bcur[h][ni];
       } else if (V >= 1) {
         for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
         for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
@@ -76,7 +91,14 @@ __global__ __launch_bounds__(256) void k(long stages, const float* __restrict__ 
         }
     }
     if (V == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (V >= 3 && V != 5) {
+    if (V == 6) {
+      float* wa = &lds[(buf ^ 1) * (BM + BN) * RS];
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + i * 64;
+        *reinterpret_cast<float4*>(wa + row * RS + (tid & 3) * 4) = ra[i];
+      }
+    }
+    if (V >= 3 && V < 5) {
       float* wa = &lds[(buf ^ 1) * (BM + BN) * RS];
       for (int i = 0; i < 2; ++i) {
 #if WMAP == 1
@@ -122,9 +144,10 @@ int main(int argc, char** argv) {
   printf("WMAP %d\n", WMAP);
   for (int blocks : {768}) {
     run<2>(blocks, stages, g, sink, lds); run<3>(blocks, stages, g, sink, lds); run<4>(blocks, stages, g, sink, lds);
-    run<5>(blocks, stages, g, sink, 2 * (BM + BN) * KB * 4);
-    run<5>(1024, stages, g, sink, 2 * (BM + BN) * KB * 4);
+    run<6>(blocks, stages, g, sink, lds);
+    run<6>(1024, stages, g, sink, lds);
     run<4>(1024, stages, g, sink, lds);
+    run<6>(768, stages, g, sink, 24 * 1024);
   }
   return 0;
 }
