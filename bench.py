@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PREMVOS_BENCH_BATCH", "4")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PREMVOS_BENCH_BATCH", "16")),
                     help="frames per step per GPU")
     ap.add_argument("--precision", default=os.environ.get("PREMVOS_BENCH_PRECISION", "fp32"),
                     choices=["fp32", "bf16x3", "bf16", "mixed-bf16x3", "mixed-bf16"],
@@ -138,7 +138,7 @@ def roofline(pipe, batch):
     traffic = None      # HBM bytes per launch from the PMC passes (profiles/r01_conv_hbm_traffic.json: method + corrections)
     import glob
     tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_hbm_traffic.json")))      # newest round last
-    if batch == 4 and tfs:
+    if batch == 16 and tfs:        # the PMC passes of tools/profile_round.sh run the default batch
         try:
             traffic = round(json.load(open(tfs[-1]))["hbm_bytes_per_launch"])
         except Exception:

@@ -34,7 +34,7 @@ class FramePipeline:
         self.refine = RefinementNet(refine_w, num_middle, device, precision=precision)
         # refinement: the boxes of `refine_group` frames form one batch of the network (bigger GEMMs fill the chip
         # better); `lanes` independent workspaces let several such calls be in flight on different streams
-        self.refine_group = max(1, min(batch, int(os.environ.get("PREMVOS_REFINE_GROUP", "4"))))
+        self.refine_group = max(1, min(batch, int(os.environ.get("PREMVOS_REFINE_GROUP", "8"))))
         n_calls = self.refine_calls_per_step = -(-batch // self.refine_group)
         self.n_refine_lanes = min(n_calls, int(os.environ.get("PREMVOS_REFINE_LANES", "2"))) if concurrent else 1
         self.masks: Optional[torch.Tensor] = None

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from oracle import proposal_oracle as PO, pwc_oracle as O, refinement_oracle as RO
 from premvos_amd.pipeline import FramePipeline
-B = 4
+B = int(os.environ.get('PREMVOS_BENCH_BATCH', '16'))
 pipe = FramePipeline(O.synth_state_dict(0), PO.synth_weights(0), PO.synth_weights(1), RO.synth_weights(0), batch=B, boxes_per_frame=20)
 fa, fb = bench.synth_frames(B, 0); fa, fb = fa.cuda(), fb.cuda(); boxes = bench.synth_boxes(B, 0).cuda()
 for _ in range(2): pipe.step(fa, fb, boxes)
