@@ -155,7 +155,8 @@ def roofline(pipe, batch):
     cb.record()
     cb.synchronize()
     ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+    return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel (every dense conv of the three nets; the seven 1-2 channel heads run "
+                                       "on conv_smalln_kernel and are counted with their algorithmic FLOPs)", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": round(alg_bytes / nl), "mfma_ceiling_measured": round(ceiling, 1),
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),

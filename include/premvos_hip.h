@@ -83,7 +83,7 @@ typedef struct premvos_conv_desc {
   float slope;          /* leaky slope     */
   int32_t out_mode;     /* PREMVOS_OUT_*   */
   int32_t cout_ps;      /* PIXSHUF2: channels per phase (cout == 4*cout_ps); out dims are 2ho x 2wo */
-  int32_t tile_hint;    /* 0 = auto; else (BM<<16)|BN to force a tile config (bench/tests) */
+  int32_t tile_hint;    /* 0 = auto; (BM<<16)|BN forces an MFMA tile config; 1 forces the direct kernel for cout <= 2 */
   int32_t split_k;      /* 0 = auto, <0 = never, >0 = force this many k-slices */
   float* workspace;     /* split-K partial slabs (may be NULL: then never split) */
   int64_t workspace_bytes;

@@ -299,6 +299,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const premvos_conv_d
 }  // namespace
 
 namespace premvos {
+bool conv_smalln_applicable(const premvos_conv_desc& d);      // conv_smalln_f32.hip
+int conv_smalln(const premvos_conv_desc& d, hipStream_t s);
 int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin) {
   const long total = ((long)d.n * d.ho * d.wo - m_begin) * d.cout;
   int g = (int)((total + 255) / 256);
@@ -479,6 +481,10 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16(d, s);
+  // 1- and 2-channel heads: per-pixel dot products, not GEMM tiles (tile_hint 0 = auto, 1 = forced; any other hint
+  // keeps them on the MFMA kernel, which is what the autotuner compares against)
+  if ((d.tile_hint == 0 || d.tile_hint == 1) && premvos::conv_smalln_applicable(d)) return premvos::conv_smalln(d, s);
+  PV_REQUIRE(d.tile_hint != 1, "conv2d: the direct small-N kernel does not apply to this layer");
   int bm, bn;
   pick_tile(d, &bm, &bn);
   if (pick_kb(d) == 32) {
@@ -504,6 +510,7 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
 extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   if (dp == nullptr || dp->k_pad <= 0 || dp->n <= 0 || dp->ho <= 0 || dp->wo <= 0 || dp->cout <= 0) return 0;
   if (dp->precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16_workspace_bytes(*dp);
+  if ((dp->tile_hint == 0 || dp->tile_hint == 1) && premvos::conv_smalln_applicable(*dp)) return 0;
   int bm, bn;
   pick_tile(*dp, &bm, &bn);
   switch ((bm << 16) | bn) {

@@ -220,6 +220,9 @@ def _candidates(d: ConvDesc):
         if d.precision == _lib.PREC_F32 and 64 < d.cout <= 96:
             tiles.append((128, 96))
     out = []
+    if d.precision == _lib.PREC_F32 and d.cout <= 2 and d.out_mode == OUT_NHWC and d.kh * d.kw * d.cin_pad >= 32 \
+            and d.cout * d.k_pad * 4 <= 150 * 1024:
+        out.append((1, 0, -1, 0, 0))               # tile_hint 1 = the direct (non-MFMA) kernel for 1-2 output channels
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((128, 128), (128, 64), (64, 128))) else [16]

@@ -171,7 +171,7 @@ def test_layout_roundtrip():
     assert v.buf[..., 37:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("case", [(1, 661, 16, 28, 128, 3, 0), (2, 1024, 6, 9, 256, 1, 0), (1, 117, 8, 14, 2, 3, 5),
+@pytest.mark.parametrize("case", [(1, 661, 16, 28, 128, 3, 0), (2, 1024, 6, 9, 256, 1, 0), (1, 117, 8, 14, 6, 3, 5),
                                   (1, 597, 32, 56, 96, 3, 3)])
 def test_conv2d_split_k_deterministic_and_exact(case):
     """Small-M / long-K layers are cut along K; result equals the unsplit kernel to fp32 round-off and is bitwise
@@ -251,3 +251,38 @@ def test_conv2d_tail_split(case):
     assert torch.equal(flat[0][:main_rows], flat[2][:main_rows])
     assert (flat[0][main_rows:] - flat[2][main_rows:]).abs().max().item() < 1e-4
     assert not torch.equal(flat[0][main_rows:], torch.zeros_like(flat[0][main_rows:]))
+
+
+@pytest.mark.parametrize("case", [(2, 565, 20, 28, 2, 3, 1, 1, False), (1, 32, 17, 23, 2, 3, 1, 1, True), (3, 256, 9, 9, 2, 1, 1, 1, False),
+                                  (1, 117, 8, 14, 1, 3, 2, 2, False), (1, 661, 16, 28, 2, 3, 1, 1, False)])
+def test_conv2d_direct_kernel_for_one_or_two_output_channels(case):
+    """cout <= 2 heads (predict_flow, dc_conv7 + residual, logits) run on the direct per-pixel kernel; same numbers as
+    the MFMA kernel (fp32 round-off: another summation order) and as torch; bit-identical from run to run."""
+    ops = _ops()
+    n, cin, h, w, cout, k, stride, dil, with_res = case
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    pad = dil * (k // 2)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    res = torch.randn(ref.shape, generator=g) if with_res else None
+    if with_res:
+        ref = ref + res.double()
+    ref = F.leaky_relu(ref, 0.1)
+    xin, pk = _to_nhwc(x, ops), ops.pack_conv(wt, b)
+    rr = _to_nhwc(res, ops) if with_res else None
+    outs = []
+    for hint in (1, 1, 0, (64 << 16) | 32):
+        out = _to_nhwc(torch.zeros(ref.shape), ops, coff=2, ps=8)
+        d = ops.conv_desc(xin, pk, out, stride=(stride, stride), dilation=(dil, dil), pad=(pad, pad), act=ops.ACT_LEAKY, res=rr,
+                          tile_hint=hint, split_k=-1)
+        if hint in (0, 1):
+            assert ops.workspace_bytes(d) == 0
+        ops.run_desc(d)
+        torch.cuda.synchronize()
+        outs.append(out.torch().cpu())
+        assert out.buf[..., :2].abs().max().item() == 0 and out.buf[..., 2 + cout:].abs().max().item() == 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert (outs[0].double() - ref).abs().max().item() < 2e-4
+    assert (outs[0] - outs[3]).abs().max().item() < 1e-4
