@@ -136,12 +136,206 @@ void run(int blocks, long stages, const float* g, float* sink, int lds_bytes) {
          hipGetErrorString(hipGetLastError()));
 }
 
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k2(long stages, const float* __restrict__ g, float* sink) {
+  constexpr int BM2 = 64 * WM, BN2 = 64 * WN, NT = 64 * WM * WN;
+  constexpr int APT = BM2 * 4 / NT, BPT = BN2 * 4 / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+  for (int i = tid; i < 2 * (BM2 + BN2) * RS; i += NT) lds[i] = 1.0f + i * 1e-7f;
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  float4 ra[APT], rb[BPT];
+  const float* gp = g + ((long)blockIdx.x * NT + tid) * 4;
+  for (long s = 0; s < stages; ++s) {
+    const int buf = s & 1;
+    for (int i = 0; i < APT; ++i) ra[i] = *reinterpret_cast<const float4*>(gp + ((s * 8 + i) & 1023) * 262144L % (1 << 24));
+    for (int i = 0; i < BPT; ++i) rb[i] = *reinterpret_cast<const float4*>(gp + ((s * 8 + 4 + i) & 1023) * 262144L % (1 << 24));
+    const float* a = &lds[buf * (BM2 + BN2) * RS + wm0 * RS + frag_off];
+    const float* b = &lds[buf * (BM2 + BN2) * RS + (BM2 + wn0) * RS + frag_off];
+#pragma unroll
+    for (int h = 0; h < KB / 8; ++h) {
+      float4 af[2], bf[2];
+      for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+      for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    float* wa = &lds[(buf ^ 1) * (BM2 + BN2) * RS];
+    for (int i = 0; i < APT; ++i) *reinterpret_cast<float4*>(wa + ((tid >> 2) + i * (NT / 4)) * RS + (tid & 3) * 4) = ra[i];
+    for (int i = 0; i < BPT; ++i) *reinterpret_cast<float4*>(wa + (BM2 + (tid >> 2) + i * (NT / 4)) * RS + (tid & 3) * 4) = rb[i];
+    __syncthreads();
+  }
+  float t = 0.f;
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+  if (t == 123.456f) sink[0] = t;
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k4(long stages, const float* __restrict__ g, float* sink) {
+  constexpr int BM2 = 64 * WM, BN2 = 64 * WN, NT = 64 * WM * WN;
+  constexpr int APT = BM2 * 4 / NT, BPT = BN2 * 4 / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+  for (int i = tid; i < 3 * (BM2 + BN2) * RS; i += NT) lds[i] = 1.0f + i * 1e-7f;
+  __syncthreads();
+  f32x16 acc[2][2];
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  float4 ra[APT], rb[BPT];
+  const float* gp = g + ((long)blockIdx.x * NT + tid) * 4;
+  for (long s = 0; s < stages; ++s) {
+    const int buf = s % 3, wbuf = (s + 2) % 3;
+    for (int i = 0; i < APT; ++i) ra[i] = *reinterpret_cast<const float4*>(gp + ((s * 8 + i) & 1023) * 262144L % (1 << 24));
+    for (int i = 0; i < BPT; ++i) rb[i] = *reinterpret_cast<const float4*>(gp + ((s * 8 + 4 + i) & 1023) * 262144L % (1 << 24));
+    const float* a = &lds[buf * (BM2 + BN2) * RS + wm0 * RS + frag_off];
+    const float* b = &lds[buf * (BM2 + BN2) * RS + (BM2 + wn0) * RS + frag_off];
+#pragma unroll
+    for (int h = 0; h < KB / 8; ++h) {
+      if (h == 1) __syncthreads();       // everyone has finished stage s-1 (its buffer is this stage's write target)
+      float4 af[2], bf[2];
+      for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+      for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    float* wa = &lds[wbuf * (BM2 + BN2) * RS];
+    for (int i = 0; i < APT; ++i) *reinterpret_cast<float4*>(wa + ((tid >> 2) + i * (NT / 4)) * RS + (tid & 3) * 4) = ra[i];
+    for (int i = 0; i < BPT; ++i) *reinterpret_cast<float4*>(wa + (BM2 + (tid >> 2) + i * (NT / 4)) * RS + (tid & 3) * 4) = rb[i];
+  }
+  float t = 0.f;
+  for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+  if (t == 123.456f) sink[0] = t;
+}
+
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WM * WN) void k3(long stages, const float* __restrict__ g, float* sink) {
+  constexpr int BM2 = 32 * MI * WM, BN2 = 32 * NI * WN, NT = 64 * WM * WN;
+  constexpr int APT = BM2 * 4 / NT, BPT = BN2 * 4 / NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * 32 * MI, wn0 = (wave % WN) * 32 * NI;
+  for (int i = tid; i < 2 * (BM2 + BN2) * RS; i += NT) lds[i] = 1.0f + i * 1e-7f;
+  __syncthreads();
+  f32x16 acc[MI][NI];
+  for (int a = 0; a < MI; ++a) for (int b = 0; b < NI; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  float4 ra[APT], rb[BPT];
+  const float* gp = g + ((long)blockIdx.x * NT + tid) * 4;
+  for (long s = 0; s < stages; ++s) {
+    const int buf = s & 1;
+    for (int i = 0; i < APT; ++i) ra[i] = *reinterpret_cast<const float4*>(gp + ((s * 8 + i) & 1023) * 262144L % (1 << 24));
+    for (int i = 0; i < BPT; ++i) rb[i] = *reinterpret_cast<const float4*>(gp + ((s * 8 + 4 + i) & 1023) * 262144L % (1 << 24));
+    const float* a = &lds[buf * (BM2 + BN2) * RS + wm0 * RS + frag_off];
+    const float* b = &lds[buf * (BM2 + BN2) * RS + (BM2 + wn0) * RS + frag_off];
+#pragma unroll
+    for (int h = 0; h < KB / 8; ++h) {
+      float4 af[MI], bf[NI];
+      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    float* wa = &lds[(buf ^ 1) * (BM2 + BN2) * RS];
+    for (int i = 0; i < APT; ++i) *reinterpret_cast<float4*>(wa + ((tid >> 2) + i * (NT / 4)) * RS + (tid & 3) * 4) = ra[i];
+    for (int i = 0; i < BPT; ++i) *reinterpret_cast<float4*>(wa + (BM2 + (tid >> 2) + i * (NT / 4)) * RS + (tid & 3) * 4) = rb[i];
+    __syncthreads();
+  }
+  float t = 0.f;
+  for (int a = 0; a < MI; ++a) for (int b = 0; b < NI; ++b) for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+  if (t == 123.456f) sink[0] = t;
+}
+
+template <int WM, int WN>
+void run2(int blocks, long stages, const float* g, float* sink) {
+  const int lds_bytes = 2 * 64 * (WM + WN) * RS * 4;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k2<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL((k2<WM, WN>), dim3(blocks), dim3(64 * WM * WN), lds_bytes, 0, stages / 8, g, sink);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL((k2<WM, WN>), dim3(blocks), dim3(64 * WM * WN), lds_bytes, 0, stages, g, sink);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double fl = (double)blocks * WM * WN * stages * 32 * 4096.0;
+  printf("tile %3dx%3d (%d waves)  blocks %4d  lds %6d B: %7.1f TF/s  %s\n", 64 * WM, 64 * WN, WM * WN, blocks, lds_bytes,
+         fl / (ms * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+}
+
+template <int WM, int WN, int MI, int NI>
+void run3(int blocks, long stages, const float* g, float* sink) {
+  const int lds_bytes = 2 * 32 * (MI * WM + NI * WN) * RS * 4;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k3<WM, WN, MI, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL((k3<WM, WN, MI, NI>), dim3(blocks), dim3(64 * WM * WN), lds_bytes, 0, stages / 8, g, sink);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL((k3<WM, WN, MI, NI>), dim3(blocks), dim3(64 * WM * WN), lds_bytes, 0, stages, g, sink);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double fl = (double)blocks * WM * WN * stages * (MI * NI * 8) * 4096.0;
+  printf("wave tile %3dx%3d, block %3dx%3d (%d waves)  blocks %4d  lds %6d B: %7.1f TF/s  %s\n", 32 * MI, 32 * NI, 32 * MI * WM,
+         32 * NI * WN, WM * WN, blocks, lds_bytes, fl / (ms * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+}
+
+template <int WM, int WN>
+void run4(int blocks, long stages, const float* g, float* sink) {
+  const int lds_bytes = 3 * 64 * (WM + WN) * RS * 4;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k4<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL((k4<WM, WN>), dim3(blocks), dim3(64 * WM * WN), lds_bytes, 0, stages / 8, g, sink);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL((k4<WM, WN>), dim3(blocks), dim3(64 * WM * WN), lds_bytes, 0, stages, g, sink);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double fl = (double)blocks * WM * WN * stages * 32 * 4096.0;
+  printf("3-buffer pipeline, tile %3dx%3d (%d waves)  blocks %4d  lds %6d B: %7.1f TF/s  %s\n", 64 * WM, 64 * WN, WM * WN, blocks,
+         lds_bytes, fl / (ms * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+}
+
 int main(int argc, char** argv) {
   float *g, *sink;
   hipMalloc(&g, (1L << 25) * 4); hipMemset(g, 0, (1L << 25) * 4); hipMalloc(&sink, 64);
   const long stages = 4000;
   const int lds = 2 * (BM + BN) * RS * 4;           // 40960 B -> 3-4 workgroups per CU
   printf("WMAP %d\n", WMAP);
+  run4<2, 2>(512, stages, g, sink); run4<2, 2>(768, stages, g, sink); run4<4, 2>(256, stages, g, sink); run4<4, 2>(512, stages, g, sink);
+  run2<2, 2>(512, stages, g, sink);
+  run3<2, 2, 2, 4>(512, stages, g, sink); run3<2, 2, 2, 4>(768, stages, g, sink);
+  run3<2, 2, 4, 2>(512, stages, g, sink); run3<2, 2, 4, 4>(256, stages, g, sink); run3<2, 2, 4, 4>(512, stages, g, sink);
+  run3<2, 2, 2, 2>(768, stages, g, sink); run3<2, 2, 1, 2>(1024, stages, g, sink);
+  run2<2, 2>(768, stages, g, sink); run2<2, 2>(1024, stages, g, sink);
+  run2<4, 2>(256, stages, g, sink); run2<4, 2>(512, stages, g, sink);
+  run2<2, 4>(512, stages, g, sink);
+  run2<4, 4>(256, stages, g, sink);
+  run2<2, 1>(1536, stages, g, sink); run2<1, 1>(3072, stages, g, sink);
   for (int blocks : {768}) {
     run<2>(blocks, stages, g, sink, lds); run<3>(blocks, stages, g, sink, lds); run<4>(blocks, stages, g, sink, lds);
     run<6>(blocks, stages, g, sink, lds);
