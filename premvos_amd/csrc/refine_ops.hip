@@ -198,10 +198,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
                                                              int c4, const float* __restrict__ wgt,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int out_ps, int ho, int wo, int pt, int pl, int act,
-                                                             int cpad) {
+                                                             int cpad, int dil) {
+  // dil > 1 (atrous, stride 1): the outputs of a tile are `dil` apart, i.e. the tile lives on one of the dil x dil
+  // sub-lattices of the output, on which the dilated conv is an ordinary 3x3 conv; tile index -> (residue, position).
   constexpr int NCOL = (TW - 1) * STRIDE + 3;
   constexpr int NROW = (TR - 1) * STRIDE + 3;
-  const int xt = (wo + TW - 1) / TW, yt = (ho + TR - 1) / TR;
+  const int xt = dil * (((wo + dil - 1) / dil + TW - 1) / TW), yt = dil * (((ho + dil - 1) / dil + TR - 1) / TR);
   const long total = (long)n * yt * xt * c4;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int cg = idx % c4;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
     const int tx = t % xt;
     t /= xt;
     const int ty = t % yt, b = t / yt;
-    const int ox0 = tx * TW, oy0 = ty * TR;
+    const int ox0 = (tx % dil) + (tx / dil) * TW * dil, oy0 = (ty % dil) + (ty / dil) * TR * dil;
     float4 k[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) k[i] = *reinterpret_cast<const float4*>(wgt + (long)i * cpad + cg * 4);
@@ -224,13 +226,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
     const float* imgp = in + ((long)b * h * w) * in_ps + cg * 4;
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
-      const int iy = iy0 + j;
+      const int iy = iy0 + j * dil;
       const bool rowok = (unsigned)iy < (unsigned)h;
       const float* rowp = imgp + ((long)iy * w) * in_ps;
       float4 v[NCOL];
 #pragma unroll
       for (int cx = 0; cx < NCOL; ++cx) {
-        const int ix = ix0 + cx;
+        const int ix = ix0 + cx * dil;
         v[cx] = (rowok && (unsigned)ix < (unsigned)w) ? *reinterpret_cast<const float4*>(rowp + (long)ix * in_ps)
                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
         if (PRE_RELU) {
@@ -249,16 +251,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
             const float4 a = v[q * STRIDE + i], kk = k[kj * 3 + i];
             acc[o][q].x += a.x * kk.x; acc[o][q].y += a.y * kk.y; acc[o][q].z += a.z * kk.z; acc[o][q].w += a.w * kk.w;
           }
-        if (kj == 2 && oy0 + o < ho) {             // this output row is complete
-          float* orow = out + (((long)b * ho + oy0 + o) * wo) * out_ps + cg * 4;
+        if (kj == 2 && oy0 + o * dil < ho) {       // this output row is complete
+          float* orow = out + (((long)b * ho + oy0 + o * dil) * wo) * out_ps + cg * 4;
 #pragma unroll
           for (int q = 0; q < TW; ++q) {
-            if (ox0 + q >= wo) break;
+            if (ox0 + q * dil >= wo) break;
             float4 r = acc[o][q];
             if (act == PREMVOS_ACT_RELU) {
               r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
             }
-            *reinterpret_cast<float4*>(orow + (long)(ox0 + q) * out_ps) = r;
+            *reinterpret_cast<float4*>(orow + (long)(ox0 + q * dil) * out_ps) = r;
           }
         }
       }
@@ -435,18 +437,21 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
              "dwconv3x3: pointers must be 16-byte aligned");
   PV_REQUIRE(act == PREMVOS_ACT_NONE || act == PREMVOS_ACT_RELU, "dwconv3x3: bad activation");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dilation == 1 && stride == 1 && wo >= 8 && ho >= 8) {   // register-tiled fast path (stride 2: row kernel wins)
+  if (stride == 1 && (wo + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3) &&
+      (ho + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3)) {   // register-tiled fast path (stride 2: row kernel wins)
     // tile: 5x5 when both extents are multiples of 5 and small (the 25x25 maps of the middle/exit flow), else 8 rows
     // x 4 columns, 4x4 when that leaves the chip short of threads
     const int c4 = c_pad / 4;
     int tr = 8, tw = 4;
-    if (ho % 5 == 0 && wo % 5 == 0 && ho <= 50) tr = tw = 5;
+    if (dilation > 1) tr = 4;                       // sub-lattices of an atrous layer are short: 4x4 tiles
+    else if (ho % 5 == 0 && wo % 5 == 0 && ho <= 50) tr = tw = 5;
     else if ((long)n * ((ho + 7) / 8) * ((wo + 3) / 4) * c4 < 256L * 1024) tr = 4;
-    const long tot = (long)n * ((ho + tr - 1) / tr) * ((wo + tw - 1) / tw) * c4;
+    const long tot = (long)n * (dilation * (((ho + dilation - 1) / dilation + tr - 1) / tr)) *
+                     (dilation * (((wo + dilation - 1) / dilation + tw - 1) / tw)) * c4;
     const dim3 g(grid_for(tot)), b(256);
 #define PV_DW_TILE(PR, ST, TW_, TR_)                                                                                  \
   hipLaunchKernelGGL((dwconv3x3_tile_kernel<PR, ST, TW_, TR_>), g, b, 0, s, in, in_ps, n, h, w, c4, wgt, bias, out,   \
-                     out_ps, ho, wo, pt, pl, act, c_pad)
+                     out_ps, ho, wo, pt, pl, act, c_pad, dilation)
 #define PV_DW_SHAPE(PR, ST)                                                                                           \
   do {                                                                                                                \
     if (tr == 5) PV_DW_TILE(PR, ST, 5, 5);                                                                            \

@@ -20,7 +20,8 @@ def _libops():
 
 @pytest.mark.parametrize("c,h,stride,rate,pre,act", [(128, 33, 1, 1, True, 0), (256, 34, 2, 1, True, 0),
                                                       (728, 25, 1, 2, False, 1), (2048, 25, 1, 18, False, 1),
-                                                      (304, 20, 1, 1, False, 1)])
+                                                      (304, 20, 1, 1, False, 1), (64, 25, 1, 6, False, 1), (32, 25, 1, 12, True, 0),
+                                                      (16, 31, 1, 3, True, 1)])
 def test_dwconv_matches_torch(c, h, stride, rate, pre, act):
     _lib, ops = _libops()
     from premvos_amd.refinement.model import PackedDW
