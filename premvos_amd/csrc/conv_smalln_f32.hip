@@ -13,17 +13,15 @@ constexpr int LPP = 16;   // lanes per output pixel
 template <int NOUT>
 __global__ __launch_bounds__(256) void conv_smalln_kernel(const premvos_conv_desc p) {
   extern __shared__ __attribute__((aligned(16))) float wl[];          // [NOUT][k_pad]
-  const int K = p.kh * p.kw * p.cin_pad;
   for (int i = threadIdx.x * 4; i < NOUT * p.k_pad; i += 256 * 4)
     *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(p.wgt + (long)(i / p.k_pad) * p.k_pad + i % p.k_pad);
   __syncthreads();
   const int sub = threadIdx.x & (LPP - 1);
   const long M = (long)p.n * p.ho * p.wo;
-  const long groups = (M + 0) ;
   const long g0 = ((long)blockIdx.x * 256 + threadIdx.x) / LPP;
   const long gstride = (long)gridDim.x * 256 / LPP;
   const int hw = p.ho * p.wo;
-  for (long m = g0; m < groups; m += gstride) {
+  for (long m = g0; m < M; m += gstride) {
     const int n = (int)(m / hw), rem = (int)(m - (long)n * hw);
     const int oy = rem / p.wo, ox = rem - oy * p.wo;
     const float* img = p.in + (long)n * p.h * p.w * p.in_ps;
@@ -77,7 +75,6 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const premvos_conv_des
       }
     }
   }
-  (void)K;
 }
 
 }  // namespace

@@ -7,7 +7,7 @@ SHAPES = {"pw1024": (8, 128, 128, 1024, 1024, 1), "mid728x4": (80, 25, 25, 728, 
           "res_1024_256": (4, 47, 84, 1024, 256, 1)}
 for name, (n, h, w, cin, cout, k) in SHAPES.items():
     x = ops.NHWC.alloc(n, h, w, cin); x.buf.normal_()
-    pk = ops.pack_conv(torch.randn(cout, cin, k, k) * 0.05, torch.zeros(cout))
+    pk = ops.pack_conv(torch.randn(cout, cin, k, k) * 0.05, torch.zeros(cout), precision=os.environ.get("PREC", "fp32"))
     out = ops.NHWC.alloc(n, h, w, cout)
     fl = 2.0 * n * h * w * cin * cout * k * k
     res = []
