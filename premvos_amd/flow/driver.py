@@ -163,7 +163,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         folders = [ln.rstrip() for ln in f if ln.rstrip()]
     t = time()
     net = pwc_dc_net(pwc_model_fn).cuda().eval()
-    stage = FlowStage(net=net, batch=1)
+    batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "8")))      # pairs per launch list (all pairs are independent)
+    stages: Dict[int, FlowStage] = {}
     print("Model setup, in", time() - t, "seconds")
     for vidx, video in enumerate(folders):
         images = sorted(glob.glob(video + "*"))
@@ -171,8 +172,26 @@ def main(argv: Optional[List[str]] = None) -> int:
         outs = [im.replace(root_dir, out).replace(".png", ".flo").replace(".jpg", ".flo") for im in images]
         os.makedirs(video.replace(root_dir, out), exist_ok=True)
         t = time()
-        for im1_fn, im2_fn, flow_fn in zip(images[:-1], images[1:], outs):
-            writeFlowFile(flow_fn, calculate_flow(stage, im1_fn, im2_fn))
+        pairs = list(zip(images[:-1], images[1:], outs))
+        frames = {}
+        for s0 in range(0, len(pairs), batch):
+            chunk = pairs[s0:s0 + batch]
+            for a, b_, _ in chunk:
+                for fn in (a, b_):
+                    if fn not in frames:
+                        frames[fn] = _imread_rgb(fn)[:, :, :3]
+            same = all(frames[a].shape == frames[chunk[0][0]].shape and frames[b_].shape == frames[chunk[0][0]].shape
+                       for a, b_, _ in chunk)
+            groups = [chunk] if same else [[c] for c in chunk]
+            for g in groups:
+                st = stages.setdefault(len(g), FlowStage(net=net, batch=len(g)))
+                im1 = torch.from_numpy(np.stack([frames[a] for a, _, _ in g])).to(st.device)
+                im2 = torch.from_numpy(np.stack([frames[b_] for _, b_, _ in g])).to(st.device)
+                flo = st.run(im1, im2).cpu().numpy()
+                for k, (_, _, flow_fn) in enumerate(g):
+                    writeFlowFile(flow_fn, flo[k])
+            for a, _, _ in chunk[:-1]:
+                frames.pop(a, None)
         n = max(len(images) - 1, 1)
         print("video", vidx, "finished in", time() - t, "seconds.", n, "images at", (time() - t) / n, "per image.")
     return 0

@@ -168,13 +168,13 @@ def detect_one_image(img: np.ndarray, model_func) -> List[SecondDetectionResult]
     raise TypeError("model_func must be a premvos_amd OfflinePredictor")
 
 
-_STAGES: Dict[int, ProposalStage] = {}
+_STAGES: Dict[tuple, ProposalStage] = {}
 
 
-def _stage_for(net: ProposalNet) -> ProposalStage:
-    if id(net) not in _STAGES:
-        _STAGES[id(net)] = ProposalStage({}, batch=1, device=net.device, net=net)
-    return _STAGES[id(net)]
+def _stage_for(net: ProposalNet, batch: int = 1) -> ProposalStage:
+    if (id(net), batch) not in _STAGES:
+        _STAGES[(id(net), batch)] = ProposalStage({}, batch=batch, device=net.device, net=net)
+    return _STAGES[(id(net), batch)]
 
 
 def convert_results_to_json(results, img_idx=None) -> List[dict]:
@@ -205,19 +205,37 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
             imgs += sorted(glob.glob(pre + "/" + s + "/*"))
     else:
         imgs = sorted(glob.glob(os.path.join(generic_images_folder, generic_images_pattern)))
-    n = 0
+    # Frames still to do, grouped into runs of equal size and pushed through the net DRIVER_BATCH at a time (the
+    # reference forwards one frame per session.run; every frame is independent, so batching changes nothing but speed)
+    todo = []
     for fn in imgs:
         seq = fn.split("/")[-2]
         out_dir = os.path.join(output_folder, seq)
         os.makedirs(out_dir, exist_ok=True)
         out_fn = os.path.join(out_dir, os.path.splitext(os.path.basename(fn))[0] + ".json")
-        if os.path.exists(out_fn):
-            continue
-        img = np.asarray(Image.open(fn).convert("RGB"))[:, :, ::-1]       # cv2.imread gives BGR (train.py:500)
-        res = convert_results_to_json(detect_one_image(np.ascontiguousarray(img), pred_func))
-        with open(out_fn, "w") as f:
-            json.dump(res, f)
-        n += 1
+        if not os.path.exists(out_fn):
+            todo.append((fn, out_fn))
+    batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "8")))
+    n, i = 0, 0
+    while i < len(todo):
+        chunk = []
+        while i < len(todo) and len(chunk) < batch:
+            img = np.asarray(Image.open(todo[i][0]).convert("RGB"))[:, :, ::-1]     # cv2.imread gives BGR (train.py:500)
+            if chunk and img.shape != chunk[0][1].shape:
+                break
+            chunk.append((todo[i][1], np.ascontiguousarray(img)))
+            i += 1
+        orig = chunk[0][1].shape[:2]
+        if isinstance(pred_func, OfflinePredictor) and len(chunk) > 1:
+            stage = _stage_for(pred_func.net, len(chunk))
+            stage.run(torch.from_numpy(np.stack([c[1][:, :, :3] for c in chunk])).to(stage.device))
+            results = [stage.detections(k, orig) for k in range(len(chunk))]
+        else:
+            results = [detect_one_image(c[1], pred_func) for c in chunk]
+        for (out_fn, _), res in zip(chunk, results):
+            with open(out_fn, "w") as f:
+                json.dump(convert_results_to_json(res), f)
+            n += 1
     return n
 
 

@@ -190,6 +190,29 @@ class RefinementEngine:
         self.valid_data = _FeedData()
         self.trainer = _FeedTrainer(self)
 
+    def refine_frames(self, images, proposal_lists):
+        """Several frames of equal size at once: the crops of all of them form one batch (``RefinementNet.refine_group``)."""
+        live = [(im, pr) for im, pr in zip(images, proposal_lists) if pr]
+        if not live:
+            return proposal_lists
+        if len(live) == 1 or max(len(pr) for _, pr in live) > self.max_boxes:
+            for im, pr in live:
+                self.refine_frame(im, pr)
+            return proposal_lists
+        P = _bucket(max(len(pr) for _, pr in live))
+        boxes = np.zeros((len(live), P, 4), np.float32)
+        for g, (_, pr) in enumerate(live):
+            boxes[g, :len(pr)] = _boxes_from_proposals(pr)
+        frames = torch.from_numpy(np.stack([np.array(im[:, :, :3], dtype=np.uint8, order="C") for im, _ in live])).to(self.net.device)
+        counts = torch.tensor([len(pr) for _, pr in live], dtype=torch.int32, device=self.net.device)
+        p = self.net.refine_group(frames, torch.from_numpy(boxes).to(self.net.device), counts)
+        masks, conf = p.mask_g.cpu().numpy(), p.conf_g.cpu().numpy()
+        for g, (_, pr) in enumerate(live):
+            for i in range(len(pr)):
+                pr[i]["segmentation"] = rle.encode(masks[g, i])
+                pr[i]["conf_score"] = str(conf[g, i])
+        return proposal_lists
+
     def refine_boxes(self, frame_u8: np.ndarray, boxes_y0x0y1x1: np.ndarray):
         """-> (mask uint8 [n,H,W], posterior f32 [n,H,W], conf f32 [n]) as numpy."""
         n = len(boxes_y0x0y1x1)
@@ -255,22 +278,33 @@ def refinement_net_init(config_path: str = "refinement_net/configs/live") -> Ref
 
 
 def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_dir: str, output_dir: str) -> int:
-    """The batch stage: every <seq>/<frame>.json of bb_input_dir -> output_dir (same relative name)."""
+    """The batch stage: every <seq>/<frame>.json of bb_input_dir -> output_dir (same relative name).  Consecutive frames of
+    equal size are refined as one batch of crops (every box is an independent example, FewShotSegmentationForwarder.py:104-110)."""
     from PIL import Image
-    n = 0
+    group = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
+    jobs = []
     for jf in sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json"))):
         rel = os.path.relpath(jf, bb_input_dir)
-        out_fn = os.path.join(output_dir, rel)
         with open(jf) as f:
             proposals = json.load(f)
-        img_fn = os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")
-        image = np.asarray(Image.open(img_fn).convert("RGB"))
-        proposals = engine.refine_frame(image, proposals)
+        image = np.asarray(Image.open(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")).convert("RGB"))
+        jobs.append((os.path.join(output_dir, rel), image, proposals))
+        if len(jobs) == group or jobs[0][1].shape != image.shape:
+            last = jobs.pop() if jobs[0][1].shape != image.shape else None
+            engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs])
+            _write_jobs(jobs)
+            jobs = [last] if last is not None else []
+    if jobs:
+        engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs])
+        _write_jobs(jobs)
+    return len(glob.glob(os.path.join(bb_input_dir, "*", "*.json")))
+
+
+def _write_jobs(jobs) -> None:
+    for out_fn, _, proposals in jobs:
         os.makedirs(os.path.dirname(out_fn), exist_ok=True)
         with open(out_fn, "w") as f:
             json.dump(proposals, f)
-        n += 1
-    return n
 
 
 def main(argv: Optional[List[str]] = None) -> int:

@@ -147,3 +147,41 @@ def test_three_frame_clip_end_to_end(tmp_path):
         assert before == {p: os.path.getmtime(p) for p in before}
     finally:
         os.chdir(cwd)
+
+
+def test_batched_drivers_equal_frame_by_frame_drivers(tmp_path, monkeypatch):
+    """PREMVOS_DRIVER_BATCH only changes how many independent frames share a launch list: same .flo payloads, same proposal
+    and refined JSON up to fp32 round-off (another batch size may pick another k-split)."""
+    from premvos_amd import rle, run_pipeline
+    from premvos_amd.flow.driver import readFlowFile
+    roots = []
+    cwd = os.getcwd()
+    try:
+        for tag, batch in (("one", "1"), ("many", "8")):
+            root = tmp_path / tag
+            root.mkdir()
+            _make_tree(root)
+            monkeypatch.setenv("PREMVOS_DRIVER_BATCH", batch)
+            assert run_pipeline.main(["--root", str(root), "--flow_weights", "weights/pwc.pth.tar", "--general_weights",
+                                      "weights/proposal_general_weights", "--specific_weights", "weights/specific.pt",
+                                      "--refinement_weights", "weights/refinement_specific_weights"]) == 0
+            os.chdir(cwd)
+            roots.append(root / "output" / "intermediate")
+    finally:
+        os.chdir(cwd)
+    a, b = roots
+    for t in range(2):
+        fa, fb = (readFlowFile(str(r / "flow" / "bear" / f"{t:05d}.flo")) for r in (a, b))
+        assert np.abs(fa - fb).max() < 1e-4
+    for t in range(3):
+        for stage in ("general_proposals", "specific_proposals"):
+            pa, pb = (json.load(open(r / stage / "bear" / f"{t:05d}.json")) for r in (a, b))
+            assert len(pa) == len(pb)
+            for x, y in zip(pa, pb):
+                assert np.abs(np.array(x["bbox"]) - np.array(y["bbox"])).max() <= 0.1001 and abs(x["score"] - y["score"]) <= 0.0101
+        ra, rb = (json.load(open(r / "refined_proposals" / "bear" / f"{t:05d}.json")) for r in (a, b))
+        assert len(ra) == len(rb)
+        for x, y in zip(ra, rb):
+            if x["bbox"] == y["bbox"]:
+                assert abs(float(x["conf_score"]) - float(y["conf_score"])) < 1e-4
+                assert (rle.decode(x["segmentation"]) != rle.decode(y["segmentation"])).mean() < 1e-3
