@@ -292,6 +292,11 @@ int64_t premvos_rle_workspace_bytes(int32_t n, int32_t h, int32_t w);
 int premvos_rle_boundaries_u8(const uint8_t* masks, int32_t n, int32_t h, int32_t w, int32_t* positions,
                               int32_t capacity, int32_t* nruns, void* workspace, void* stream);
 
+/* Host-side utility (no GPU work): COCO rleToString of `n` run lengths into `out` (capacity `cap` bytes); returns the
+ * length or -1 -- the "counts" string of every mask the refinement / merge stages write
+ * (forwarding/FewShotSegmentationForwarder.py:141-142). */
+int64_t premvos_rle_counts_to_string_host(const int64_t* counts, int64_t n, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

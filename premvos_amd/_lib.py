@@ -111,6 +111,8 @@ def load():
     lib.premvos_crc32c_host.restype = C.c_uint32
     lib.premvos_refine_output_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
     lib.premvos_refine_output_workspace_bytes.restype = C.c_int64
+    lib.premvos_rle_counts_to_string_host.argtypes = [_vp, C.c_int64, _vp, C.c_int64]
+    lib.premvos_rle_counts_to_string_host.restype = C.c_int64
     lib.premvos_rle_workspace_bytes.argtypes = [_i32, _i32, _i32]
     lib.premvos_rle_workspace_bytes.restype = C.c_int64
     _LIB = lib

@@ -204,3 +204,24 @@ extern "C" int premvos_rle_boundaries_u8(const uint8_t* masks, int32_t n, int32_
                      nruns);
   return premvos::check_launch("rle_write");
 }
+
+// Host utility (no GPU): COCO maskApi rleToString -- run lengths (delta-coded against the run two back from the 4th on) in
+// 5-bit groups, LSB first, 0x20 = continuation, +48.  Returns the string length (without terminator), or -1 if `cap` is
+// too small.  The Python twin (premvos_amd/rle.py:counts_to_string) is the reference for tests; this one is ~100x faster.
+extern "C" int64_t premvos_rle_counts_to_string_host(const int64_t* counts, int64_t n, char* out, int64_t cap) {
+  int64_t p = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    long long x = counts[i];
+    if (i > 2) x -= counts[i - 2];
+    bool more = true;
+    while (more) {
+      char c = (char)(x & 0x1f);
+      x >>= 5;                                  // arithmetic shift
+      more = (c & 0x10) ? x != -1 : x != 0;
+      if (more) c |= 0x20;
+      if (p >= cap) return -1;
+      out[p++] = (char)(c + 48);
+    }
+  }
+  return p;
+}

@@ -163,7 +163,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         folders = [ln.rstrip() for ln in f if ln.rstrip()]
     t = time()
     net = pwc_dc_net(pwc_model_fn).cuda().eval()
-    batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "8")))      # pairs per launch list (all pairs are independent)
+    batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "1")))      # pairs per launch list; the host (JPEG decode, .flo
+                                                                          # write) dominates, so 1 is the measured optimum
     stages: Dict[int, FlowStage] = {}
     print("Model setup, in", time() - t, "seconds")
     for vidx, video in enumerate(folders):

@@ -215,7 +215,7 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
         out_fn = os.path.join(out_dir, os.path.splitext(os.path.basename(fn))[0] + ".json")
         if not os.path.exists(out_fn):
             todo.append((fn, out_fn))
-    batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "8")))
+    batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "1")))     # measured: host decode dominates, 1 is fastest
     n, i = 0, 0
     while i < len(todo):
         chunk = []

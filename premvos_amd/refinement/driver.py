@@ -206,10 +206,11 @@ class RefinementEngine:
         frames = torch.from_numpy(np.stack([np.array(im[:, :, :3], dtype=np.uint8, order="C") for im, _ in live])).to(self.net.device)
         counts = torch.tensor([len(pr) for _, pr in live], dtype=torch.int32, device=self.net.device)
         p = self.net.refine_group(frames, torch.from_numpy(boxes).to(self.net.device), counts)
-        masks, conf = p.mask_g.cpu().numpy(), p.conf_g.cpu().numpy()
+        conf = p.conf_g.cpu().numpy()
+        segs = _encode_on_gpu(p.mask_g.view(-1, *p.mask_g.shape[2:]))        # run boundaries on the GPU, no mask D2H
         for g, (_, pr) in enumerate(live):
             for i in range(len(pr)):
-                pr[i]["segmentation"] = rle.encode(masks[g, i])
+                pr[i]["segmentation"] = segs[g * P + i]
                 pr[i]["conf_score"] = str(conf[g, i])
         return proposal_lists
 
@@ -239,12 +240,18 @@ class RefinementEngine:
             chunk = boxes[s:s + self.max_boxes]
             P = self.max_boxes if len(proposals) > self.max_boxes else _bucket(len(chunk))
             p = self.net.refine(frame, torch.from_numpy(chunk).to(self.net.device), max_boxes=P)
-            masks = p.mask[:len(chunk)].cpu().numpy()
             conf = p.conf[:len(chunk)].cpu().numpy()
+            segs = _encode_on_gpu(p.mask[:len(chunk)])
             for i in range(len(chunk)):
-                proposals[s + i]["segmentation"] = rle.encode(masks[i])
+                proposals[s + i]["segmentation"] = segs[i]
                 proposals[s + i]["conf_score"] = str(conf[i])
         return proposals
+
+
+def _encode_on_gpu(masks: torch.Tensor) -> List[dict]:
+    """COCO RLE of uint8 CUDA masks [n,H,W] (same strings as rle.encode; premvos_rle_boundaries_u8 + host differencing)."""
+    from ..mergetrack import encode_masks
+    return encode_masks(masks)
 
 
 def _bucket(n: int) -> int:

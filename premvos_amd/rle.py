@@ -25,6 +25,17 @@ def counts_from_mask(mask: np.ndarray) -> np.ndarray:
 
 
 def counts_to_string(counts) -> str:
+    if len(counts) > 64:              # long run lists: the C twin in libpremvos_hip.so (same algorithm, no GPU involved)
+        try:
+            import ctypes as C
+            from . import _lib
+            arr = np.ascontiguousarray(counts, dtype=np.int64)
+            buf = C.create_string_buffer(13 * len(arr) + 1)
+            n = _lib.load().premvos_rle_counts_to_string_host(arr.ctypes.data, len(arr), buf, len(buf))
+            if n >= 0:
+                return buf.raw[:n].decode("ascii")
+        except Exception:                  # noqa: BLE001 -- library not built yet: the pure-python path below is equivalent
+            pass
     out = bytearray()
     cl = [int(c) for c in counts]
     for i, x in enumerate(cl):

@@ -1,0 +1,52 @@
+"""Dev tool: file-to-file throughput of the stage drivers (JPEG decode, .flo / JSON / RLE included) on a synthetic 480p sequence
+with full-depth nets:  python tools/time_drivers.py [frames=24]"""
+import json, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from PIL import Image
+from oracle import proposal_oracle as PO, pwc_oracle as O, refinement_oracle as RO, reid_oracle as QO
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+root = tempfile.mkdtemp()
+os.chdir(root)
+sd = "data/DAVIS/JPEGImages/480p/seq"
+os.makedirs(sd)
+for i in range(T):
+    pair = O.synth_frame_pair(480, 856, seed=5, shift=(1.5 * i, -0.5 * i))
+    Image.fromarray((pair[0, 3:, :, :854].permute(1, 2, 0) * 255).round().to(torch.uint8).numpy()).save(f"{sd}/{i:05d}.jpg", quality=95)
+open("seq_to_run.txt", "w").write("data/DAVIS/JPEGImages/480p/seq/\n")
+os.makedirs("weights")
+torch.save({"state_dict": O.synth_state_dict(0)}, "weights/pwc.pth.tar")
+torch.save(PO.synth_weights(0), "weights/general.pt"); torch.save(PO.synth_weights(1), "weights/specific.pt")
+torch.save(RO.synth_weights(0), "weights/refine.pt"); torch.save(QO.synth_weights(0), "weights/reid.pt")
+os.makedirs("code/ReID_net/configs")
+json.dump({"model": "Re-ID", "load": os.path.abspath("weights/reid.pt")}, open("code/ReID_net/configs/run", "w"))
+from premvos_amd import run_pipeline
+import premvos_amd.run_pipeline as rp
+# time each stage by running the pipeline and watching directory creation order through a patched print
+t0 = time.time()
+stamps = {}
+orig = os.path.isdir
+def stage_time(name, fn):
+    torch.cuda.synchronize(); t = time.time(); fn(); torch.cuda.synchronize(); stamps[name] = time.time() - t
+from premvos_amd.flow import driver as fd
+from premvos_amd.proposal import driver as pd
+from premvos_amd.proposal.combine import combine
+from premvos_amd.refinement import driver as rd
+from premvos_amd.reid import driver as qd
+inter = "output/intermediate"
+for rep in ("cold", "warm"):            # cold = plan building + autotuning included; warm = second sequence-equivalent
+    os.system(f"rm -rf {root}/output")
+    stage_time(f"flow/{rep}", lambda: fd.main(["seq_to_run.txt", "weights/pwc.pth.tar", f"{inter}/flow"]))
+    for name, wf in (("general_proposals", "weights/general.pt"), ("specific_proposals", "weights/specific.pt")):
+        stage_time(f"{name}/{rep}", lambda: pd.main(["--forward", f"{inter}/{name}", "--agnostic", "--second_head", "--forward_dataset", "DAVIS",
+                                                     "--load", wf, "--davis_name", os.path.join(os.getcwd(), "seq_to_run.txt")]))
+    combine(inter + "/")
+    if rep == "cold":
+        w = rd.load_weights("weights/refine.pt"); r_eng = rd.RefinementEngine(rd.RefinementNet(w, rd.infer_num_middle(w)))
+        q_eng = qd.engine_from_config(qd.Config("code/ReID_net/configs/run"))
+    stage_time(f"refinement/{rep}", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_proposals/"))
+    stage_time(f"reid/{rep}", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_proposals/", f"{inter}/ReID_proposals/"))
+nprops = sum(len(json.load(open(f"{inter}/combined_proposals/seq/{i:05d}.json"))) for i in range(T)) / T
+print(f"{T} frames 480x854, {nprops:.1f} combined proposals per frame; DRIVER_BATCH={os.environ.get('PREMVOS_DRIVER_BATCH', 'default')}")
+for k, v in stamps.items():
+    print(f"  {k:28s} {v:7.2f} s  = {T / v:6.1f} frames/s")
