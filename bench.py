@@ -178,10 +178,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+        # RCCL ("nccl") is the product path; PREMVOS_BENCH_BACKEND=gloo lets the multi-rank logic be exercised by several
+        # processes sharing ONE GPU (RCCL refuses two ranks on the same device)
+        dist.init_process_group(os.environ.get("PREMVOS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == a.gpus or world == 1, (world, a.gpus)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local if local < torch.cuda.device_count() else 0)
     torch.cuda.set_device(dev)
 
     # oracle modules are used here ONLY as generators of synthetic weights / frames (no checkpoint, no DAVIS)

@@ -38,3 +38,4 @@ def test_bench_line_through_the_distributed_path():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 20 < r["achieved"] < r["mfma_ceiling_measured"] <= 160
     assert "workload" in d["config"] and "model" not in d["config"]
+
