@@ -59,7 +59,7 @@ int premvos_abi_version(void);
  *   proposal_net/basemodel.py:51-99 (Conv2D+BNReLU bottlenecks), proposal_net/model.py:30-51,
  *   refinement_net/network/deeplab/core/xception.py:154-178 (pointwise halves), model.py:383-433.
  *
- * Weights are pre-packed by the host (premvos_amd/packing.py) as a row-major matrix
+ * Weights are pre-packed by the host (premvos_amd/ops.py: pack_conv) as a row-major matrix
  * wgt[cout_pad][k_pad], k = (kh*KW + kw)*cin_pad + c, cin_pad = roundup(cin,4),
  * k_pad = roundup(KH*KW*cin_pad, 16), cout_pad = roundup(cout, 32); zero filled padding.
  * ---------------------------------------------------------------------------------------- */
@@ -134,6 +134,14 @@ int premvos_corr_nchw_fwd_f32(const float* in1, const float* in2, float* out, in
 int premvos_warp_fwd_f32(const float* x, int32_t x_ps, const float* flow, int32_t flow_ps, float flow_scale,
                          float* out, int32_t out_ps, int32_t n, int32_t h, int32_t w, int32_t c,
                          void* stream);
+
+/* The two calls above fused for pyramid levels 5..2 (PWCNet.py:207-208, 220-221, ...: warp5 = self.warp(c25, up_flow5*0.625);
+ * corr5 = self.corr(c15, warp5)): the image-2 features x2 are warped while the cost-volume kernel stages its f2 tile, so
+ * the warped map is never written to HBM.  Bit-identical to premvos_warp_fwd_f32 followed by premvos_corr_fwd_f32.
+ * md must be 4. */
+int premvos_warp_corr_fwd_f32(const float* f1, int32_t f1_ps, const float* x2, int32_t x2_ps, const float* flow,
+                              int32_t flow_ps, float flow_scale, float* out, int32_t out_ps, int32_t n, int32_t h,
+                              int32_t w, int32_t c, int32_t md, float slope, int32_t copy_f1, void* stream);
 
 /* layout plumbing at the stage edges (the reference nets take/return NCHW) */
 int premvos_nchw_to_nhwc_f32(const float* in, float* out, int32_t out_ps, int32_t n, int32_t c, int32_t h,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "premvos_conv2d_f32": [C.POINTER(ConvDesc), _vp],
     "premvos_corr_fwd_f32": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "premvos_corr_nchw_fwd_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "premvos_warp_corr_fwd_f32": [_vp, _i32, _vp, _i32, _vp, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32,
+                                  _i32, _vp],
     "premvos_warp_fwd_f32": [_vp, _i32, _vp, _i32, _f32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "premvos_nchw_to_nhwc_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "premvos_nhwc_to_nchw_f32": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp],

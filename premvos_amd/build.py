@@ -23,6 +23,18 @@ def sources() -> "list[str]":
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _file_flags(src: str) -> "list[str]":
+    """Extra flags a source asks for in a leading ``// hipcc-flags: ...`` comment line."""
+    out = []
+    with open(src) as f:
+        for line in f:
+            if not line.startswith("//"):
+                break
+            if line.startswith("// hipcc-flags:"):
+                out += [t for t in line[len("// hipcc-flags:"):].split() if t.startswith("-")]
+    return out
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -48,7 +60,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))),
                 os.path.getmtime(os.path.join(HERE, "..", "include", "premvos_hip.h"))):
-            cmd = [hipcc, *flags, "-c", src, "-o", obj]
+            cmd = [hipcc, *flags, *_file_flags(src), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -1,0 +1,194 @@
+// PWC-Net cost volume for the instantiation the network uses (md = 4 -> 9x9 = 81 displacements, kernel 1,
+// strides 1; PWCNet.py:69), LDS-tiled for gfx950.
+//
+// What it replaces: corr_cuda_kernel.cu:59-127 (one 32-thread block per output pixel, the f1 pixel in shared
+// memory, a serial loop over the 81 displacements with a per-thread partial sum and a serial final reduce) plus the
+// two blob_rearrange passes and the two zero fills of corr_cuda.c:52-63.
+//
+// Design (HBM-bound: f1 and f2 are read once, the 81 (+C copied) floats of a pixel are written once):
+//   * a workgroup owns an 8 x 32 pixel tile of one image; the (8+8) x (32+8) halo of f2 is staged in LDS 16 channels
+//     at a time with a 20-float pixel stride (5 x 16 B, odd: ds_read_b128 of 16 consecutive pixels is conflict-free);
+//   * one thread owns one pixel: its f1 channels sit in registers, its 81 sums in 81 accumulators; per chunk it reads
+//     81 x 4 float4 from LDS for 81 x 16 FMAs (one LDS read per 4 FMAs -- the LDS pipe, not HBM, would bound a
+//     naive "one lane per displacement" mapping);
+//   * the sums leave through LDS so that the 81 floats of a pixel go out as one contiguous run (two passes of 45 / 36
+//     displacement rows reuse the f2 tile's LDS); LeakyReLU(0.1) (PWCNet.py:198) and the torch.cat copy of c1
+//     (PWCNet.py:213) are fused as before.
+//   * WARP: f2 is not read but produced on the fly by the backward bilinear warp of image-2 features by the
+//     up-sampled flow (PWCDCNet.warp, PWCNet.py:140-176: same float sequence as warp_kernel in flow_ops.hip), so the
+//     warped feature map never exists in HBM.
+// hipcc-flags: -fno-slp-vectorize   (the SLP pass packs neighbouring displacements into v_pk_fma_f32 at the price of
+// ~1100 register moves and odd-width LDS reads per chunk: 3x slower)
+#include <type_traits>
+
+#include "common.h"
+#include "warp_math.h"
+
+namespace {
+
+constexpr int T_H = 8, T_W = 32, MD = 4, D = 2 * MD + 1;
+constexpr int HALO_H = T_H + 2 * MD, HALO_W = T_W + 2 * MD;
+constexpr int CCH = 16;            // channels per LDS chunk
+constexpr int PSTR = CCH + 4;      // padded pixel stride (floats)
+constexpr int LDS_FLOATS = HALO_H * HALO_W * PSTR;   // 12 800 floats = 51 200 B -> 3 workgroups per CU
+constexpr int ROWS_A = 5;          // displacement rows of the first output pass (5 x 9 = 45 floats per pixel)
+static_assert(256 * ROWS_A * D <= LDS_FLOATS, "output staging must fit the f2 tile's LDS");
+
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // 16 bytes at 4-byte alignment
+
+template <bool WARP>
+__global__ __launch_bounds__(256, 3) void corr81_tile_kernel(const float* __restrict__ f1, int f1_ps,
+                                                          const float* __restrict__ f2, int f2_ps,
+                                                          const float* __restrict__ flow, int flow_ps, float fscale,
+                                                          float* __restrict__ out, int out_ps, int h, int w, int c,
+                                                          float slope, int copy_f1, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int tid = threadIdx.x;
+  const int tx = tid & 31, ty = tid >> 5;
+  // Tile order: the dispatcher places workgroup b on XCD b % 8 (private 4 MB L2 each).  Give every XCD a contiguous run of
+  // the (image, tile row, tile column) raster, so that the tiles sharing f2 halo rows / columns read them through ONE L2
+  // (with the plain order 55 % of the f2 requests missed L2: 2.2x the algorithmic fetch).  Pure speed, any order is correct.
+  int tile;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
+  }
+  const int n = tile / (tiles_x * tiles_y), trem = tile - n * (tiles_x * tiles_y);
+  const int x0 = (trem % tiles_x) * T_W, y0 = (trem / tiles_x) * T_H;
+  const int x = x0 + tx, y = y0 + ty;
+  const bool valid = x < w && y < h;
+  const long img = (long)n * h * w;
+  const float* a_ptr = f1 + (img + (long)(valid ? y : 0) * w + (valid ? x : 0)) * f1_ps;
+
+  float acc[D * D];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) acc[i] = 0.f;
+
+  for (int k0 = 0; k0 < c; k0 += CCH) {
+    if (k0) __syncthreads();       // every wave is done reading the previous chunk
+    // ---- stage the f2 halo tile: 640 pixels x 4 float4 = 10 per thread, all loads issued before the first LDS write
+    constexpr int NSTG = HALO_H * HALO_W * (CCH / 4) / 256;
+    static_assert(NSTG * 256 == HALO_H * HALO_W * (CCH / 4), "staging loop must divide evenly");
+    // (out-of-range lanes load from a clamped address and are zeroed when written to LDS: a select on a register with
+    //  a load in flight would force the wave to wait for that load before issuing the next one)
+    float4 v[NSTG];
+    auto halo = [&](int j, int& slot, long& pix, int& ch, int& gy, int& gx) {
+      const int i = tid + j * 256;
+      const int px = i >> 2, q = i & 3;
+      const int hy = px / HALO_W, hx = px - hy * HALO_W;
+      gy = y0 + hy - MD, gx = x0 + hx - MD;
+      ch = k0 + q * 4;
+      slot = px * PSTR + q * 4;
+      const bool ok = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w && ch < c;
+      pix = img + (long)(ok ? gy : 0) * w + (ok ? gx : 0);
+      if (!ok) ch = 0;
+      return ok;
+    };
+#pragma unroll
+    for (int j = 0; j < NSTG; ++j) {
+      int slot, ch, gy, gx;
+      long pix;
+      halo(j, slot, pix, ch, gy, gx);
+      if constexpr (WARP) {
+        const float* fl = flow + pix * flow_ps;
+        v[j] = premvos::warp_sample4(f2 + img * f2_ps + ch, f2_ps, fl[0] * fscale, fl[1] * fscale, gx, gy, h, w);
+      } else {
+        v[j] = *reinterpret_cast<const float4*>(f2 + pix * f2_ps + ch);
+      }
+    }
+    float4 a[CCH / 4];
+#pragma unroll
+    for (int q = 0; q < CCH / 4; ++q) a[q] = *reinterpret_cast<const float4*>(a_ptr + (valid && k0 + q * 4 < c ? k0 + q * 4 : 0));
+#pragma unroll
+    for (int j = 0; j < NSTG; ++j) {
+      int slot, ch, gy, gx;
+      long pix;
+      const bool ok = halo(j, slot, pix, ch, gy, gx);
+      *reinterpret_cast<float4*>(&lds[slot]) = ok ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < CCH / 4; ++q) {
+      const bool ok = valid && k0 + q * 4 < c;
+      if (!ok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // torch.cat((corr, c1, ...)) (PWCNet.py:213): c1 goes out straight from the registers (the window starts 81 floats
+      // into the pixel, so only 4-byte alignment is known)
+      if (copy_f1 && ok) *reinterpret_cast<f4u*>(out + (img + (long)y * w + x) * out_ps + D * D + k0 + q * 4) = f4u{a[q].x, a[q].y, a[q].z, a[q].w};
+    }
+    __syncthreads();
+    // ---- 81 displacements x 16 channels ------------------------------------------------------
+    const float* base = &lds[(ty * HALO_W + tx) * PSTR];
+    // per (displacement row, 4-channel group): 9 independent LDS reads in flight, then 9 independent FMA chains
+#pragma unroll
+    for (int dy = 0; dy < D; ++dy)
+#pragma unroll
+      for (int q = 0; q < CCH / 4; ++q) {
+        float4 b[D];
+#pragma unroll
+        for (int dx = 0; dx < D; ++dx) b[dx] = *reinterpret_cast<const float4*>(base + (dy * HALO_W + dx) * PSTR + q * 4);
+#pragma unroll
+        for (int dx = 0; dx < D; ++dx) {
+          float s = acc[dy * D + dx];
+          s = fmaf(a[q].x, b[dx].x, s);
+          s = fmaf(a[q].y, b[dx].y, s);
+          s = fmaf(a[q].z, b[dx].z, s);
+          s = fmaf(a[q].w, b[dx].w, s);
+          acc[dy * D + dx] = s;
+        }
+      }
+  }
+
+  // ---- mean over C (sum / (float)sumelems, corr_cuda_kernel.cu:124-126), LeakyReLU, coalesced runs ----------------
+  // A power-of-two C divides exactly by multiplying with 1/C (same bits as the IEEE division, a tenth of the instructions).
+  const float fc = (float)c;
+  const bool pow2 = (c & (c - 1)) == 0;
+  const float rc = 1.0f / fc;
+  const int wave = tid >> 6, lane = tid & 63;
+  auto stage = [&](auto e0_, auto ne_) {          // this thread's sums e0 .. e0+ne -> lds[pixel][ne]
+    constexpr int e0 = decltype(e0_)::value, ne = decltype(ne_)::value;
+    if (pow2) {
+#pragma unroll
+      for (int e = 0; e < ne; ++e) {
+        const float v = acc[e0 + e] * rc;
+        lds[tid * ne + e] = v < 0.f ? v * slope : v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < ne; ++e) {
+        const float v = acc[e0 + e] / fc;
+        lds[tid * ne + e] = v < 0.f ? v * slope : v;
+      }
+    }
+  };
+  auto flush = [&](int e0, int ne) {          // lds[pixel][ne] -> out[pixel][e0 .. e0+ne): one wave per pixel run
+    __syncthreads();
+    for (int p = wave; p < T_H * T_W; p += 4) {          // wave-uniform: the pixel arithmetic runs on the scalar unit
+      const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+      if (yy < h && xx < w && lane < ne) out[(img + (long)yy * w + xx) * out_ps + e0 + lane] = lds[p * ne + lane];
+    }
+  };
+  __syncthreads();                                   // f2 tile no longer needed
+  using std::integral_constant;
+  stage(integral_constant<int, 0>{}, integral_constant<int, ROWS_A * D>{});
+  flush(0, ROWS_A * D);
+  __syncthreads();
+  stage(integral_constant<int, ROWS_A * D>{}, integral_constant<int, (D - ROWS_A) * D>{});
+  flush(ROWS_A * D, (D - ROWS_A) * D);
+}
+
+}  // namespace
+
+namespace premvos {
+int corr81_tile(const float* f1, int f1_ps, const float* f2, int f2_ps, const float* flow, int flow_ps, float fscale,
+                float* out, int out_ps, int n, int h, int w, int c, float slope, int copy_f1, hipStream_t s) {
+  const int tx = cdiv(w, T_W), ty = cdiv(h, T_H);
+  const dim3 grid(tx * ty * n);
+  if (flow != nullptr)
+    hipLaunchKernelGGL(corr81_tile_kernel<true>, grid, dim3(256), 0, s, f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out,
+                       out_ps, h, w, c, slope, copy_f1, tx, ty);
+  else
+    hipLaunchKernelGGL(corr81_tile_kernel<false>, grid, dim3(256), 0, s, f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out,
+                       out_ps, h, w, c, slope, copy_f1, tx, ty);
+  return check_launch("corr81_tile");
+}
+}  // namespace premvos

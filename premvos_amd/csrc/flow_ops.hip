@@ -3,14 +3,20 @@
 // Reference call sites: see include/premvos_hip.h.
 #include "common.h"
 #include "resize_cv.h"
+#include "warp_math.h"
 
 using premvos::cv_lin_coef;
 using premvos::cv_lin_coef_f;
 
+namespace premvos {
+int corr81_tile(const float* f1, int f1_ps, const float* f2, int f2_ps, const float* flow, int flow_ps, float fscale,
+                float* out, int out_ps, int n, int h, int w, int c, float slope, int copy_f1, hipStream_t s);   // corr_tile.hip
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// Cost volume, NHWC in / NHWC slice out.  One thread per (pixel, displacement) with the
+// Cost volume, NHWC in / NHWC slice out (general md; md = 4 runs the LDS-tiled kernel of corr_tile.hip).  One thread per (pixel, displacement) with the
 // displacement index fastest: the 81 outputs of a pixel are one coalesced 324-byte run, the
 // f1 row is a wave-wide broadcast and neighbouring displacements read neighbouring f2 pixels
 // (16-byte loads, served from L1/L2: each f2 pixel is touched by 81 displacements).
@@ -94,8 +100,8 @@ __global__ __launch_bounds__(256) void corr_nchw_kernel(const float* __restrict_
 // Backward bilinear warp x validity mask (PWCNet.py:140-176).  The float sequence mirrors
 // the reference: grid = 2*(x+u)/max(W-1,1)-1, then grid_sample's align_corners=True
 // un-normalisation ((g+1)/2)*(W-1), floor, corner weights (x1-ix)*(y1-iy) ...; the mask is
-// the sum of the in-bounds corner weights thresholded at 0.9999.  One thread per (pixel, 4 ch).
-#pragma clang fp contract(off)
+// the sum of the in-bounds corner weights thresholded at 0.9999 (warp_math.h).  One thread per (pixel, 4 ch).
+#pragma clang fp contract(off)   // from here to the end of the file (warp, cv2-exact pre/post processing)
 __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, int x_ps,
                                                    const float* __restrict__ flow, int flow_ps, float fscale,
                                                    float* __restrict__ out, int out_ps, int npix, int h, int w,
@@ -107,37 +113,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ x, 
     const int n = pix / hw, rem = pix - n * hw;
     const int py = rem / w, px = rem - py * w;
     const float u = flow[(long)pix * flow_ps] * fscale, v = flow[(long)pix * flow_ps + 1] * fscale;
-    const float wm = (float)(w - 1 > 1 ? w - 1 : 1), hm = (float)(h - 1 > 1 ? h - 1 : 1);
-    const float gx = 2.0f * ((float)px + u) / wm - 1.0f;
-    const float gy = 2.0f * ((float)py + v) / hm - 1.0f;
-    const float ix = ((gx + 1.f) / 2.f) * (float)(w - 1);
-    const float iy = ((gy + 1.f) / 2.f) * (float)(h - 1);
-    const float fx0 = floorf(ix), fy0 = floorf(iy);
-    const float fx1 = fx0 + 1.f, fy1 = fy0 + 1.f;
-    const float wnw = (fx1 - ix) * (fy1 - iy), wne = (ix - fx0) * (fy1 - iy);
-    const float wsw = (fx1 - ix) * (iy - fy0), wse = (ix - fx0) * (iy - fy0);
-    // float compare keeps huge |flow| (beyond int range) out of bounds without UB
-    const bool x0ok = fx0 >= 0.f && fx0 <= (float)(w - 1), x1ok = fx1 >= 0.f && fx1 <= (float)(w - 1);
-    const bool y0ok = fy0 >= 0.f && fy0 <= (float)(h - 1), y1ok = fy1 >= 0.f && fy1 <= (float)(h - 1);
-    const int x0 = x0ok ? (int)fx0 : 0, x1 = x1ok ? (int)fx1 : 0;
-    const int y0 = y0ok ? (int)fy0 : 0, y1 = y1ok ? (int)fy1 : 0;
-    const float* base = x + (long)n * hw * x_ps + cg * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float msum = 0.f;
-    auto tap = [&](bool ok, int yy, int xx, float wt) {
-      if (!ok) return;
-      const float4 vv = *reinterpret_cast<const float4*>(base + ((long)yy * w + xx) * x_ps);
-      acc.x += vv.x * wt;
-      acc.y += vv.y * wt;
-      acc.z += vv.z * wt;
-      acc.w += vv.w * wt;
-      msum += wt;
-    };
-    tap(y0ok && x0ok, y0, x0, wnw);
-    tap(y0ok && x1ok, y0, x1, wne);
-    tap(y1ok && x0ok, y1, x0, wsw);
-    tap(y1ok && x1ok, y1, x1, wse);
-    if (!(msum >= 0.9999f)) acc = make_float4(0.f, 0.f, 0.f, 0.f);  // NaN-safe: mask<0.9999 -> 0
+    const float4 acc = premvos::warp_sample4(x + (long)n * hw * x_ps + cg * 4, x_ps, u, v, px, py, h, w);
     *reinterpret_cast<float4*>(out + (long)pix * out_ps + cg * 4) = acc;
   }
 }
@@ -255,11 +231,30 @@ extern "C" int premvos_corr_fwd_f32(const float* f1, int32_t f1_ps, const float*
   PV_REQUIRE(premvos::aligned16(f1) && premvos::aligned16(f2), "corr: inputs must be 16-byte aligned");
   const int d2 = (2 * md + 1) * (2 * md + 1);
   PV_REQUIRE(out_ps >= d2 + (copy_f1 ? c : 0), "corr: out_ps too small");
+  if (md == 4)   // the PWC-Net instantiation: LDS-tiled kernel (corr_tile.hip)
+    return premvos::corr81_tile(f1, f1_ps, f2, f2_ps, nullptr, 0, 0.f, out, out_ps, n, h, w, c, slope, copy_f1,
+                                static_cast<hipStream_t>(stream));
   const int npix = n * h * w;
   hipLaunchKernelGGL(corr_nhwc_kernel, dim3(premvos::cdiv(npix, CORR_PIX)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), f1, f1_ps, f2, f2_ps, out, out_ps, npix, h, w, c, md, slope,
                      copy_f1);
   return premvos::check_launch("corr_nhwc");
+}
+
+extern "C" int premvos_warp_corr_fwd_f32(const float* f1, int32_t f1_ps, const float* x2, int32_t x2_ps,
+                                         const float* flow, int32_t flow_ps, float flow_scale, float* out,
+                                         int32_t out_ps, int32_t n, int32_t h, int32_t w, int32_t c, int32_t md,
+                                         float slope, int32_t copy_f1, void* stream) {
+  PV_REQUIRE(f1 && x2 && flow && out, "warp_corr: null pointer");
+  PV_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "warp_corr: bad dims");
+  PV_REQUIRE(md == 4, "warp_corr: only md = 4 (the PWC-Net instantiation, PWCNet.py:69) is implemented");
+  PV_REQUIRE(c % 4 == 0 && f1_ps % 4 == 0 && x2_ps % 4 == 0 && f1_ps >= c && x2_ps >= c,
+             "warp_corr: C and pixel strides must be multiples of 4");
+  PV_REQUIRE(premvos::aligned16(f1) && premvos::aligned16(x2), "warp_corr: inputs must be 16-byte aligned");
+  PV_REQUIRE(flow_ps >= 2, "warp_corr: flow needs 2 channels");
+  PV_REQUIRE(out_ps >= 81 + (copy_f1 ? c : 0), "warp_corr: out_ps too small");
+  return premvos::corr81_tile(f1, f1_ps, x2, x2_ps, flow, flow_ps, flow_scale, out, out_ps, n, h, w, c, slope, copy_f1,
+                              static_cast<hipStream_t>(stream));
 }
 
 extern "C" int premvos_corr_nchw_fwd_f32(const float* in1, const float* in2, float* out, int32_t n, int32_t c,

@@ -318,6 +318,17 @@ def corr(f1: NHWC, f2: NHWC, out: NHWC, md: int = 4, slope: float = 1.0, copy_f1
     return out
 
 
+def warp_corr(f1: NHWC, x2: NHWC, flow: NHWC, scale: float, out: NHWC, md: int = 4, slope: float = 1.0,
+              copy_f1: bool = False):
+    """corr(f1, warp(x2, flow * scale)) in one kernel (bit-identical to the two calls)."""
+    assert (f1.n, f1.h, f1.w, f1.c) == (x2.n, x2.h, x2.w, x2.c) and flow.c == 2
+    assert (f1.n, f1.h, f1.w) == (flow.n, flow.h, flow.w)
+    _lib.check(_lib.load().premvos_warp_corr_fwd_f32(f1.ptr, f1.ps, x2.ptr, x2.ps, flow.ptr, flow.ps, scale, out.ptr,
+                                                     out.ps, f1.n, f1.h, f1.w, f1.c, md, slope, int(copy_f1),
+                                                     _lib.current_stream()), "warp_corr")
+    return out
+
+
 def corr_nchw(in1: torch.Tensor, in2: torch.Tensor, pad_size: int, kernel_size: int, max_displacement: int,
               stride1: int, stride2: int, corr_multiply: int = 1) -> torch.Tensor:
     """Op-level twin of ``corr_cuda_forward`` on NCHW tensors (allocates the output itself, like

@@ -27,69 +27,67 @@ from .model import RefinementNet
 
 
 class Config:
-    """core/Config.py:5-91 -- JSON file whose '#' comment lines are blanked; typed getters that do NOT coerce: a value of
-    the wrong JSON type raises TypeError, a missing key without a default fails its assertion (same as the reference).
-    ``update_config_string`` (main.py's second argument) is a JSON object merged on top."""
+    """The refinement_net config file: a JSON object in which lines starting with '#' are comments, optionally overlaid
+    by a second JSON object (main.py's update string), read through typed getters.
+
+    Interface contract taken from refinement_net/core/Config.py:5-91 and pinned by tests/golden/host_refs.json (generated
+    by running that class): getters never coerce -- a stored value of another JSON type raises TypeError (bool is an int
+    for Python, so ``int("flag")`` accepts it, as there); a missing key needs a default (AssertionError otherwise); a
+    default of the wrong type is an AssertionError even when the key exists; list getters check every element.
+    """
+
+    _SCALARS = {"bool": bool, "string": str, "int": int, "float": float, "dict": dict}
+    _LISTS = {"int_list": int, "float_list": float, "string_list": str}
 
     def __init__(self, filename: str, update_config_string: str = ""):
-        lines = [ln if not ln.strip().startswith("#") else "\n" for ln in open(filename).readlines()]
-        self._entries = json.loads("".join(lines), object_pairs_hook=OrderedDict)
+        with open(filename) as f:
+            text = "".join("\n" if ln.lstrip().startswith("#") else ln for ln in f)
+        self._entries = json.loads(text, object_pairs_hook=OrderedDict)
         if update_config_string:
             self._entries.update(json.loads(update_config_string, object_pairs_hook=OrderedDict))
 
-    def has(self, key):
+    def has(self, key) -> bool:
         return key in self._entries
 
-    def _value(self, key, dtype, default):
-        if default is not None:
-            assert isinstance(default, dtype)
-        if key in self._entries:
-            val = self._entries[key]
-            if isinstance(val, dtype):
-                return val
+    def _get(self, key, elem_type, default, as_list: bool):
+        """One getter for all types: ``as_list`` -> a list whose items are ``elem_type``; else a single ``elem_type``."""
+        def conforms(v):
+            return (isinstance(v, list) and all(isinstance(x, elem_type) for x in v)) if as_list else isinstance(v, elem_type)
+        assert default is None or conforms(default)
+        if key not in self._entries:
+            assert default is not None
+            return default
+        v = self._entries[key]
+        if as_list:
+            assert conforms(v)
+        elif not conforms(v):
             raise TypeError()
-        assert default is not None
-        return default
+        return v
 
-    def _list_value(self, key, dtype, default):
-        if default is not None:
-            assert isinstance(default, list)
-            for x in default:
-                assert isinstance(x, dtype)
-        if key in self._entries:
-            val = self._entries[key]
-            assert isinstance(val, list)
-            for x in val:
-                assert isinstance(x, dtype)
-            return val
-        assert default is not None
-        return default
-
-    def bool(self, key, default=None): return self._value(key, bool, default)
-    def string(self, key, default=None): return self._value(key, str, default)
-    def int(self, key, default=None): return self._value(key, int, default)
-    def float(self, key, default=None): return self._value(key, float, default)
-    def dict(self, key, default=None): return self._value(key, dict, default)
-    def int_list(self, key, default=None): return self._list_value(key, int, default)
-    def float_list(self, key, default=None): return self._list_value(key, float, default)
-    def string_list(self, key, default=None): return self._list_value(key, str, default)
+    def __getattr__(self, name):
+        # bool / string / int / float / dict / int_list / float_list / string_list (key, default=None)
+        if name in Config._SCALARS:
+            t = Config._SCALARS[name]
+            return lambda key, default=None: self._get(key, t, default, False)
+        if name in Config._LISTS:
+            t = Config._LISTS[name]
+            return lambda key, default=None: self._get(key, t, default, True)
+        raise AttributeError(name)
 
     def int_key_dict(self, key, default=None):
-        if default is not None:
-            assert isinstance(default, dict) and all(isinstance(k, int) for k in default)
-        dict_str = self.string(key, "")
-        if dict_str == "":
-            assert default is not None
-            res = default
-        else:
-            import ast
-            res = ast.literal_eval(dict_str)
-        assert isinstance(res, dict) and all(isinstance(k, int) for k in res)
-        return res
+        """A dict with integer keys, stored as the *string* of a Python literal (JSON keys cannot be ints)."""
+        import ast
+        text = self._get(key, str, "", False)
+        out = ast.literal_eval(text) if text else default
+        assert out is not None
+        assert isinstance(out, dict) and all(isinstance(k, int) for k in out)
+        assert default is None or (isinstance(default, dict) and all(isinstance(k, int) for k in default))
+        return out
 
-    def dir(self, key, default=None):
-        p = self.string(key, default)
-        return p if p[-1] == "/" else p + "/"
+    def dir(self, key, default=None) -> str:
+        """A directory path, always with a trailing '/'."""
+        path = self._get(key, str, default, False)
+        return path if path.endswith("/") else path + "/"
 
 
 def _boxes_from_proposals(proposals: List[dict]) -> np.ndarray:

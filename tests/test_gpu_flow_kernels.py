@@ -114,6 +114,59 @@ def test_corr_matches_oracle(c, h, w):
     assert out.buf[..., :4].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("c,h,w", [(64, 64, 112), (96, 19, 70), (20, 9, 33)])
+def test_corr_tiled_multi_tile_shapes(c, h, w):
+    """Several 8x32 tiles per image incl. ragged right / bottom tiles and a partial last 16-channel chunk; no copy of f1,
+    no LeakyReLU (slope 1)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(c * h + w)
+    f1 = torch.randn((3, c, h, w), generator=g)
+    f2 = torch.randn((3, c, h, w), generator=g)
+    ref = O.correlation_torch(f1, f2)
+    out = ops.NHWC.alloc(3, h, w, 81 + 3)
+    out.buf.fill_(7.0)
+    ops.corr(_to_nhwc(f1, ops), _to_nhwc(f2, ops), out.slice(0, 81), 4, 1.0, False)
+    torch.cuda.synchronize()
+    got = out.slice(0, 81).torch().cpu()
+    assert (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.all(out.buf[..., 81:] == 7.0)          # nothing written beyond the 81 channels
+
+
+def test_corr_general_md_falls_back():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    f1 = torch.randn((1, 8, 12, 20), generator=g)
+    f2 = torch.randn((1, 8, 12, 20), generator=g)
+    ref = torch.from_numpy(O.correlation_np(f1.numpy(), f2.numpy(), 2, 1, 2, 1, 1))
+    out = ops.NHWC.alloc(1, 12, 20, 25)
+    ops.corr(_to_nhwc(f1, ops), _to_nhwc(f2, ops), out, 2, 1.0, False)
+    torch.cuda.synchronize()
+    assert (out.torch().cpu() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("c,h,w,mag", [(128, 16, 28, 3.0), (32, 40, 75, 6.0), (64, 8, 14, 1e9)])
+def test_warp_corr_fused_is_bit_identical_to_warp_then_corr(c, h, w, mag):
+    """premvos_warp_corr_fwd_f32 == premvos_warp_fwd_f32 -> premvos_corr_fwd_f32 (PWCNet.py:207-208), every bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(c + w)
+    f1 = torch.randn((2, c, h, w), generator=g)
+    x2 = torch.randn((2, c, h, w), generator=g)
+    flo = torch.randn((2, 2, h, w), generator=g) * mag
+    flo[0, :, 0, 0] = 0.0
+    a, x, f = _to_nhwc(f1, ops), _to_nhwc(x2, ops), _to_nhwc(flo, ops)
+    wbuf = ops.NHWC.alloc(2, h, w, c)
+    two = ops.NHWC.alloc(2, h, w, 81 + c)
+    one = ops.NHWC.alloc(2, h, w, 81 + c)
+    ops.warp(x, f, 1.25, wbuf)
+    ops.corr(a, wbuf, two, 4, 0.1, True)
+    ops.warp_corr(a, x, f, 1.25, one, 4, 0.1, True)
+    torch.cuda.synchronize()
+    assert torch.equal(one.buf, two.buf)
+    ref = F.leaky_relu(O.correlation_torch(f1, O.warp(x2, flo * 1.25)), 0.1)
+    bad = (one.slice(0, 81).torch().cpu() - ref).abs() > 1e-5 * (1 + ref.abs())
+    assert bad.float().mean().item() < 1e-3          # samples at the 0.9999 mask threshold / a cell edge may flip
+
+
 def test_corr_reference_known_answer():
     """test/test.py:76-77: correlation(0,1,0,1,1,1) on [[1,2],[3,4]] x [[5,6],[7,8]] = [[5,12],[21,32]];
     :81: correlation(1,1,1,1,1,1) gives 1x9x2x2."""

@@ -127,61 +127,3 @@ def test_full_size_frame_properties():
     for i in range(20):
         assert np.array_equal(rle.decode(segs[i]), wn[i])
     assert segs[5] == rle.encode(wn[5])
-
-
-def _prop(mask, score=0.9, reid=None, **kw):
-    d = {"segmentation": rle.encode(mask), "bbox": rle.to_bbox(rle.encode(mask)), "score": score,
-         "ReID": np.zeros(128) if reid is None else reid}
-    d.update(kw)
-    return d
-
-
-def test_merge_scores_selection_and_overlap_rules():
-    """The host functions of the merge stage on hand-checkable inputs (merge_functions.py:38-76,96-149,243-248)."""
-    from premvos_amd import mergetrack as MT
-    a = np.zeros((8, 10), np.uint8); a[1:5, 1:5] = 1            # 16 px
-    b = np.zeros((8, 10), np.uint8); b[3:7, 3:9] = 1            # 24 px, overlaps a in 2x2 = 4 px
-    e1 = np.zeros(128); e1[0] = 5.0                             # |e1 - 0| = 5 -> ReID score 1 - 5/25 = 0.8
-    templates = [_prop(a, score=1.0, id=1), _prop(b, score=0.75, reid=e1, id=2)]
-    props = [_prop(a, score=0.9), _prop(b, score=0.6, reid=e1), _prop(np.zeros_like(a), score=0.5, reid=np.inf * np.ones(128))]
-    s = MT.calculate_scores(props, templates)
-    assert s.shape == (5, 2, 3)
-    assert np.allclose(s[0], [[0.8, 0.2, 0.0]] * 2)                                        # objectness (score - .5) / .5
-    assert np.allclose(s[1], [[1.0, 0.8, 0.0], [0.8, 1.0, 0.0]])                           # ReID; infinite distance -> 0
-    assert np.allclose(s[2], [[0.2, 0.0, 1.0], [0.0, 0.2, 1.0]])                           # 1 - best OTHER template
-    iou_ab = 4.0 / (16 + 24 - 4)
-    assert np.allclose(s[3], [[1.0, iou_ab, 0.0], [0.5 * iou_ab, 0.5, 0.0]])               # warp IoU x (score-.5)/.5
-    assert np.allclose(s[4], [[1 - 0.5 * iou_ab, 0.5, 1.0], [0.0, 1 - iou_ab, 1.0]])
-    nw = MT.WEIGHTS / MT.WEIGHTS.sum()
-    weighted = np.dot(nw, s.transpose((1, 0, 2)))
-    obj = np.dot(np.array([1, 1]), s[:2].transpose((1, 0, 2)))
-    sel = MT.calculate_selected_props(list(props), weighted, templates, MT.SCORE_THRESH, obj)
-    assert [p["id"] for p in sel] == [1, 2] and sel[0]["segmentation"] == props[0]["segmentation"]
-    assert sel[1]["segmentation"] == props[1]["segmentation"] and np.isclose(sel[0]["object_score"], 1.8)
-    # nothing beats the threshold -> the empty proposal
-    sel0 = MT.calculate_selected_props(list(props), np.full((2, 3), -1.0), templates, MT.SCORE_THRESH, obj)
-    assert all(rle.area(p["segmentation"]) == 0 and p["final_score"] == MT.SCORE_THRESH for p in sel0)
-    # overlap: the higher final score keeps the contested 2x2 block
-    out = MT.remove_mask_overlap(sel)
-    hi, lo = (0, 1) if sel[0]["final_score"] > sel[1]["final_score"] else (1, 0)
-    assert out[hi]["mask"].sum() == (16, 24)[hi] and out[lo]["mask"].sum() == (16, 24)[lo] - 4
-    assert (out[0]["mask"] & out[1]["mask"]).sum() == 0 and [p["id"] for p in out] == [1, 2]
-    nxt = [dict(p, ReID=np.ones(128)) for p in out]
-    upd = MT.update_templates(templates, nxt)
-    assert np.array_equal(upd[1]["ReID"], e1) and upd[0]["id"] == 1 and np.array_equal(nxt[1]["ReID"], np.ones(128))
-
-
-def test_palette_png_round_trip(tmp_path):
-    from PIL import Image
-    from premvos_amd import mergetrack as MT
-    lab = np.zeros((6, 7), np.uint8); lab[1:3, 1:4] = 1; lab[3:5, 2:6] = 7
-    MT.save_with_pascal_colormap(str(tmp_path / "a.png"), lab)
-    im = Image.open(tmp_path / "a.png")
-    assert im.mode == "P" and np.array_equal(np.array(im), lab)
-    pal = np.array(im.getpalette()[:24]).reshape(8, 3)
-    assert pal[1].tolist() == [128, 0, 0] and pal[2].tolist() == [0, 128, 0] and pal[7].tolist() == [128, 128, 128]
-    t = MT.read_ann(str(tmp_path / "a.png"))
-    assert [x["id"] for x in t] == [1, 7] and t[0]["bbox"].tolist() == [1.0, 1.0, 3.0, 2.0] and t[1]["score"] == 1.0
-    MT.save_pngs([{"mask": (lab == 1).astype(np.uint8), "id": 3}, {"mask": (lab == 7).astype(np.uint8), "id": 5}],
-                 str(tmp_path / "out" / "b.png"))
-    assert set(np.unique(np.array(Image.open(tmp_path / "out" / "b.png")))) == {0, 3, 5}

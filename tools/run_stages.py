@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Counterpart of simple_run.sh:21-58 for the stages on the hot path (A flow, B proposals x2, C combine, D refinement),
-with the script's own directory-exists resume (`if [ ! -d ... ]`).  Run from the PReMVOS root: same relative inputs
+"""DEV HARNESS (not product code; used by tests/test_gpu_plumbing.py and tools/time_drivers.py): chains the stage drivers
+like simple_run.sh:21-68 for the stages on the hot path (A flow, B proposals x2, C combine, D refinement, + the ReID batch
+stage), with the script's own directory-exists resume.  MergeTrack (simple_run.sh:70-77) is out of scope and keeps running
+from the reference on these outputs.  Original docstring: counterpart of simple_run.sh:21-58 (`if [ ! -d ... ]`).  Run from the PReMVOS root: same relative inputs
 (seq_to_run.txt, data/DAVIS/JPEGImages/480p/<seq>/) and outputs (output/intermediate/{flow,general_proposals,
 specific_proposals,combined_proposals,refined_proposals}/<seq>/...) that the unchanged ReID and MergeTrack stages read.
 
@@ -14,6 +16,8 @@ import argparse
 import os
 import sys
 from typing import List, Optional
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main(argv: Optional[List[str]] = None) -> int:
@@ -66,23 +70,9 @@ def main(argv: Optional[List[str]] = None) -> int:
         eng = qd.engine_from_config(cfg)
         qd.forward_directory(eng, "data/DAVIS/JPEGImages/480p/", refined + "/", reid + "/")
         done.append("ReID_proposals")
-    final = "output/final"
-    if not os.path.isdir(final) and os.path.isdir(reid) and os.path.exists(a.reid_config):       # :70-77
-        from premvos_amd import mergetrack
-        from premvos_amd.refinement import driver as rd
-        from premvos_amd.reid import driver as qd
-        w = rd.load_weights(a.refinement_weights)
-        r_eng = rd.RefinementEngine(rd.RefinementNet(w, rd.infer_num_middle(w)))
-        cfg = qd.Config(a.reid_config)
-        base = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(a.reid_config))))
-        if not os.path.isabs(cfg.str("load")):
-            cfg._entries["load"] = os.path.normpath(os.path.join(base, cfg.str("load")))
-        mergetrack.merge_all(r_eng, qd.engine_from_config(cfg))
-        done.append("final")
     print("stages run:", done)
     return 0
 
 
 if __name__ == "__main__":
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.exit(main())

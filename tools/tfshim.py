@@ -1,0 +1,543 @@
+"""A numpy/torch EAGER stand-in for the slice of TensorFlow 1.x + tensorpack (+ cv2 / pycocotools import stubs) that the
+reference's proposal_net graph code touches, so that the reference's OWN python (basemodel.py, model.py, train.py's
+Model._build_graph, eval.py, common.py, data.py) can be imported and EXECUTED in the build container, where neither
+TensorFlow 1.8 nor tensorpack@6fdde15 exists (tools/make_golden_tf.py turns the results into tests/golden fixtures).
+
+What this pins and what it does not: every line of the reference's composition -- which op feeds which, paddings, strides,
+crops, reshapes, box arithmetic, variable names and shapes -- runs as written.  The PRIMITIVES (conv2d, batch norm,
+max-pool, top_k, non_max_suppression, crop_and_resize, ...) are this file's restatement of the published TF 1.8 /
+tensorpack semantics; they are third-party code absent from /root/reference and stay unpinned.  Tie-breaking the TF docs
+leave open (top_k(sorted=False) order, equal scores in NMS) is fixed as: descending score, ties to the lower index.
+
+Dev / test-generation tool only: nothing under premvos_amd/ or tests/ imports it.
+"""
+from __future__ import annotations
+
+import contextlib
+import functools
+import sys
+import types
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tensors
+
+
+class DType:
+    def __init__(self, np_dtype):
+        self.np = np.dtype(np_dtype)
+
+    @property
+    def base_dtype(self):
+        return self
+
+    def __eq__(self, o):
+        return isinstance(o, DType) and self.np == o.np
+
+    def __ne__(self, o):
+        return not self == o
+
+    def __hash__(self):
+        return hash(self.np)
+
+
+float32, int32, int64, uint8, bool_ = DType(np.float32), DType(np.int32), DType(np.int64), DType(np.uint8), DType(np.bool_)
+
+
+class TShape(tuple):
+    @property
+    def ndims(self):
+        return len(self)
+
+    def as_list(self):
+        return list(self)
+
+
+def _np(x, like=None):
+    """Operand -> ndarray; python / numpy scalars take the dtype of the tensor they meet (TF converts constants)."""
+    if isinstance(x, T):
+        return x.a
+    if like is not None and np.isscalar(x) or isinstance(x, (list, tuple, np.ndarray)) and like is not None:
+        arr = np.asarray(x)
+        if arr.dtype.kind in "fiub" and like.dtype.kind == "f":
+            return arr.astype(like.dtype)
+        if arr.dtype.kind in "iu" and like.dtype.kind in "iu":
+            return arr.astype(like.dtype)
+        return arr
+    return np.asarray(x)
+
+
+class T:
+    """Eager tensor: a numpy array with TF's shape / dtype attributes and operators that keep float32 float32."""
+    __array_priority__ = 1000
+
+    def __init__(self, a, dtype=None):
+        a = a.a if isinstance(a, T) else a
+        self.a = np.asarray(a, dtype=dtype.np if isinstance(dtype, DType) else dtype)
+
+    shape = property(lambda s: TShape(s.a.shape))
+    dtype = property(lambda s: DType(s.a.dtype))
+
+    def get_shape(self):
+        return self.shape
+
+    def _b(self, o, f, rev=False):
+        o = _np(o, self.a)
+        return T(f(o, self.a) if rev else f(self.a, o))
+
+    __add__ = lambda s, o: s._b(o, np.add)
+    __radd__ = lambda s, o: s._b(o, np.add, True)
+    __sub__ = lambda s, o: s._b(o, np.subtract)
+    __rsub__ = lambda s, o: s._b(o, np.subtract, True)
+    __mul__ = lambda s, o: s._b(o, np.multiply)
+    __rmul__ = lambda s, o: s._b(o, np.multiply, True)
+    __truediv__ = lambda s, o: s._b(o, np.true_divide)
+    __rtruediv__ = lambda s, o: s._b(o, np.true_divide, True)
+    __floordiv__ = lambda s, o: s._b(o, np.floor_divide)
+    __gt__ = lambda s, o: s._b(o, np.greater)
+    __ge__ = lambda s, o: s._b(o, np.greater_equal)
+    __lt__ = lambda s, o: s._b(o, np.less)
+    __le__ = lambda s, o: s._b(o, np.less_equal)
+    __neg__ = lambda s: T(-s.a)
+    __getitem__ = lambda s, k: T(s.a[k])
+    __len__ = lambda s: len(s.a)
+    __int__ = lambda s: int(s.a)
+    __index__ = lambda s: int(s.a)
+    __bool__ = lambda s: bool(s.a)
+    __float__ = lambda s: float(s.a)
+
+    def __iter__(self):
+        return (T(x) for x in self.a)
+
+
+def _ints(shape):
+    if isinstance(shape, T):
+        return [int(v) for v in np.atleast_1d(shape.a)]
+    return [int(v) for v in shape]
+
+
+NAMED: Dict[str, T] = {}          # tensors the graph code gave a name= (the reference's fetch points)
+
+
+def _named(t: T, name) -> T:
+    if name:
+        NAMED[name] = t
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# scopes and variables
+
+_SCOPE: List[str] = []
+VARIABLES: Dict[str, np.ndarray] = {}     # filled by the caller: full variable name -> array in TF layout
+REQUESTED: List[tuple] = []               # (name, shape) of every variable the reference code asked for, in order
+
+
+@contextlib.contextmanager
+def variable_scope(name=None, default_name=None, values=None, reuse=None):
+    n = name if isinstance(name, str) else default_name
+    _SCOPE.append(n)
+    try:
+        yield types.SimpleNamespace(name="/".join(_SCOPE))
+    finally:
+        _SCOPE.pop()
+
+
+@contextlib.contextmanager
+def name_scope(name=None, *a, **k):
+    yield name
+
+
+def get_variable(name, shape) -> T:
+    full = "/".join(_SCOPE + [name])
+    shape = tuple(int(s) for s in shape)
+    REQUESTED.append((full, shape))
+    if full not in VARIABLES:
+        raise KeyError(f"variable {full} {shape} was requested by the reference code but not provided")
+    v = np.asarray(VARIABLES[full], np.float32)
+    assert v.shape == shape, (full, v.shape, shape)
+    return T(v)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tf.* ops (only what the proposal_net inference graph calls)
+
+def _tf_module():
+    tf = types.ModuleType("tensorflow")
+    tf.float32, tf.int32, tf.int64, tf.uint8, tf.bool = float32, int32, int64, uint8, bool_
+    tf.Tensor = T
+    tf.variable_scope, tf.name_scope = variable_scope, name_scope
+    tf.identity = lambda x, name=None: _named(T(x), name)
+    tf.stop_gradient = lambda x, name=None: x
+    tf.constant = lambda v, dtype=None, name=None, shape=None: _named(T(v, dtype), name)
+    tf.cast = lambda x, dtype, name=None: _named(T(_np(x).astype(dtype.np)), name)
+    tf.to_float = lambda x, name=None: T(_np(x).astype(np.float32))
+    tf.to_int32 = lambda x, name=None: T(_np(x).astype(np.int32))
+    tf.shape = lambda x, name=None: T(np.array(_np(x).shape, np.int32))
+    tf.size = lambda x, name=None: T(np.int32(_np(x).size))
+    tf.reshape = lambda x, shape, name=None: _named(T(_np(x).reshape(_ints(shape))), name)
+    tf.transpose = lambda x, perm=None, name=None: T(np.transpose(_np(x), perm))
+    tf.squeeze = lambda x, axis=None, name=None: T(np.squeeze(_np(x), axis=axis))
+    tf.expand_dims = lambda x, axis, name=None: T(np.expand_dims(_np(x), axis))
+    tf.tile = lambda x, multiples, name=None: T(np.tile(_np(x), _ints(multiples)))
+    tf.stack = lambda vals, axis=0, name=None: T(np.stack([_np(v) for v in vals], axis))
+    tf.concat = lambda vals, axis, name=None: _named(T(np.concatenate([_np(v) for v in vals], axis)), name)
+    tf.split = lambda x, n, axis=0, name=None: [T(p) for p in np.split(_np(x), n, axis)]
+    tf.range = lambda *a, **k: T(np.arange(*[int(v) for v in a], dtype=np.int32))
+    tf.zeros = lambda shape, dtype=float32, name=None: T(np.zeros(_ints(shape), dtype.np))
+    tf.zeros_like = lambda x, dtype=None, name=None: T(np.zeros_like(_np(x), dtype=dtype.np if dtype else None))
+
+    def reverse(x, axis, name=None):
+        return _named(T(np.flip(_np(x), tuple(_ints(axis)))), name)
+    tf.reverse = reverse
+
+    def _binary(f):
+        def op(x, y, name=None):
+            tx = x if isinstance(x, T) else (T(_np(x, _np(y))))
+            return _named(tx._b(y, f), name)
+        return op
+    tf.maximum, tf.minimum = _binary(np.maximum), _binary(np.minimum)
+    tf.add, tf.multiply, tf.div, tf.truediv = _binary(np.add), _binary(np.multiply), _binary(np.true_divide), _binary(np.true_divide)
+    tf.equal, tf.logical_and = _binary(np.equal), _binary(np.logical_and)
+    tf.exp = lambda x, name=None: T(np.exp(_np(x)))
+    tf.log = lambda x, name=None: T(np.log(_np(x)))
+    tf.sigmoid = lambda x, name=None: _named(T((1.0 / (1.0 + np.exp(-_np(x).astype(np.float32)))).astype(np.float32)), name)
+    tf.reduce_all = lambda x, axis=None, name=None: T(np.all(_np(x), axis=axis))
+    tf.argmax = lambda x, axis=None, name=None: T(np.argmax(_np(x), axis=axis).astype(np.int64))
+
+    def reduce_mean(x, axis=None, name=None, keepdims=False):
+        a = _np(x)
+        if a.size == 0:
+            out = np.zeros(np.mean(np.zeros([max(s, 1) for s in a.shape]), axis=tuple(axis) if axis is not None else None,
+                                   keepdims=keepdims).shape[:0] + tuple(s for i, s in enumerate(a.shape) if axis is None or i not in axis),
+                           np.float32)
+            return _named(T(out), name)
+        return _named(T(a.mean(axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis, keepdims=keepdims, dtype=np.float32)), name)
+    tf.reduce_mean = reduce_mean
+    tf.gather = lambda p, idx, name=None: _named(T(_np(p)[_np(idx).astype(np.int64)]), name)
+
+    def gather_nd(p, idx, name=None):
+        i = _np(idx).astype(np.int64)
+        return _named(T(_np(p)[tuple(i[..., k] for k in range(i.shape[-1]))]), name)
+    tf.gather_nd = gather_nd
+    tf.boolean_mask = lambda x, m, name=None: T(_np(x)[_np(m).astype(bool)])
+    tf.where = lambda c, name=None: T(np.argwhere(_np(c)).astype(np.int64))
+
+    def sparse_to_dense(sparse_indices, output_shape, sparse_values, default_value, name=None):
+        out = np.full(_ints(output_shape), default_value)
+        out[_np(sparse_indices).astype(np.int64)] = sparse_values
+        return T(out)
+    tf.sparse_to_dense = sparse_to_dense
+
+    def map_fn(f, elems, dtype=None, parallel_iterations=None):
+        n = len(_np(elems[0]))
+        return T(np.stack([_np(f(tuple(T(_np(e)[i]) for e in elems))) for i in range(n)])) if n else T(np.zeros((0,), dtype.np))
+    tf.map_fn = map_fn
+    tf.cond = lambda pred, t, f: t() if bool(_np(pred)) else f()
+
+    def slice_(x, begin, size, name=None):
+        a = _np(x)
+        idx = tuple(slice(b, None if s == -1 else b + s) for b, s in zip(_ints(begin), _ints(size)))
+        return _named(T(a[idx]), name)
+    tf.slice = slice_
+    tf.pad = lambda x, paddings, name=None: T(np.pad(_np(x), [tuple(p) for p in paddings]))
+    tf.random_normal_initializer = tf.variance_scaling_initializer = tf.zeros_initializer = lambda *a, **k: None
+
+    nn = types.ModuleType("tensorflow.nn")
+    nn.relu = lambda x, name=None: _named(T(np.maximum(_np(x), np.float32(0))), name)
+
+    def softmax(x, name=None):
+        a = _np(x).astype(np.float32)
+        if a.size == 0:
+            return _named(T(a), name)
+        e = np.exp(a - a.max(axis=-1, keepdims=True))
+        return _named(T((e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)), name)
+    nn.softmax = softmax
+
+    def top_k(x, k=1, sorted=True, name=None):       # noqa: A002
+        a = _np(x)
+        order = np.argsort(-a.astype(np.float64) if a.dtype.kind == "f" else -a.astype(np.int64), kind="stable")[:int(k)]
+        return T(a[order]), T(order.astype(np.int32))
+    nn.top_k = top_k
+
+    def avg_pool(x, ksize, strides, padding, data_format="NHWC"):
+        assert data_format == "NCHW" and list(ksize) == [1, 1, 2, 2] and list(strides) == [1, 1, 2, 2]
+        a = _np(x)
+        assert a.shape[2] % 2 == 0 and a.shape[3] % 2 == 0          # SAME == VALID for even maps
+        return T(F.avg_pool2d(torch.from_numpy(np.ascontiguousarray(a)), 2).numpy())
+    nn.avg_pool = avg_pool
+    tf.nn = nn
+
+    image = types.ModuleType("tensorflow.image")
+
+    def non_max_suppression(boxes, scores, max_output_size, iou_threshold=0.5, name=None):
+        """non_max_suppression_op.cc: candidates by descending score; a candidate is dropped when its IoU with an already
+        selected box is > iou_threshold; corners are min/max-normalised, area <= 0 gives IoU 0."""
+        b, s = _np(boxes).astype(np.float32), _np(scores)
+        order = np.argsort(-s.astype(np.float64), kind="stable")
+        y1, x1 = np.minimum(b[:, 0], b[:, 2]), np.minimum(b[:, 1], b[:, 3])
+        y2, x2 = np.maximum(b[:, 0], b[:, 2]), np.maximum(b[:, 1], b[:, 3])
+        area = (y2 - y1) * (x2 - x1)
+        keep: List[int] = []
+        for i in order:
+            if len(keep) >= int(max_output_size):
+                break
+            ok = True
+            for j in keep:
+                if area[i] <= 0 or area[j] <= 0:
+                    continue
+                ih = np.float32(max(np.float32(min(y2[i], y2[j]) - max(y1[i], y1[j])), np.float32(0)))
+                iw = np.float32(max(np.float32(min(x2[i], x2[j]) - max(x1[i], x1[j])), np.float32(0)))
+                inter = np.float32(ih * iw)
+                if inter / np.float32(np.float32(area[i] + area[j]) - inter) > np.float32(iou_threshold):
+                    ok = False
+                    break
+            if ok:
+                keep.append(int(i))
+        return T(np.array(keep, np.int32))
+    image.non_max_suppression = non_max_suppression
+
+    def crop_and_resize(img, boxes, box_ind, crop_size, method="bilinear", extrapolation_value=0, name=None):
+        """crop_and_resize_op.cc (NHWC): in_y = y1*(H-1) + i*(y2-y1)*(H-1)/(crop-1); samples outside [0, H-1] give the
+        extrapolation value; bilinear: top + (bottom - top) * y_lerp with top/bottom lerped in x."""
+        im, bx = _np(img).astype(np.float32), _np(boxes).astype(np.float32)
+        n, (ch, cw) = len(bx), _ints(crop_size)
+        _, H, W, C = im.shape
+        out = np.full((n, ch, cw, C), np.float32(extrapolation_value), np.float32)
+        f = np.float32
+        for b in range(n):
+            y1, x1, y2, x2 = bx[b]
+            src = im[int(_np(box_ind)[b])]
+            hs = f((y2 - y1) * f(H - 1) / f(ch - 1)) if ch > 1 else f(0)
+            ws = f((x2 - x1) * f(W - 1) / f(cw - 1)) if cw > 1 else f(0)
+            for i in range(ch):
+                iy = f(y1 * f(H - 1) + f(i) * hs) if ch > 1 else f(0.5) * (y1 + y2) * f(H - 1)
+                if iy < 0 or iy > H - 1:
+                    continue
+                t, bt = int(np.floor(iy)), int(np.ceil(iy))
+                ly = f(iy - f(t))
+                for j in range(cw):
+                    ix = f(x1 * f(W - 1) + f(j) * ws) if cw > 1 else f(0.5) * (x1 + x2) * f(W - 1)
+                    if ix < 0 or ix > W - 1:
+                        continue
+                    l, r = int(np.floor(ix)), int(np.ceil(ix))
+                    lx = f(ix - f(l))
+                    top = src[t, l] + (src[t, r] - src[t, l]) * lx
+                    bot = src[bt, l] + (src[bt, r] - src[bt, l]) * lx
+                    out[b, i, j] = top + (bot - top) * ly
+        return T(out)
+    image.crop_and_resize = crop_and_resize
+    tf.image = image
+    tf.summary = types.SimpleNamespace(image=lambda *a, **k: None, scalar=lambda *a, **k: None)
+    tf.losses = types.SimpleNamespace()
+    tf.get_variable = lambda name, *a, **k: None
+    tf.train = types.SimpleNamespace()
+    return tf
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tensorpack layers (models/*.py @6fdde15): Layer(name, input, ...) opens variable_scope(name); argscope defaults
+
+_ARGSCOPE: List[Dict[str, dict]] = [{}]
+
+
+@contextlib.contextmanager
+def argscope(layers, **kw):
+    layers = layers if isinstance(layers, (list, tuple)) else [layers]
+    new = {k: dict(v) for k, v in _ARGSCOPE[-1].items()}
+    for layer in layers:
+        new.setdefault(layer.__name__, {}).update(kw)
+    _ARGSCOPE.append(new)
+    try:
+        yield
+    finally:
+        _ARGSCOPE.pop()
+
+
+def get_arg_scope():
+    return _ARGSCOPE[-1]
+
+
+def layer_register(log_shape=False, use_scope=True):
+    def deco(func):
+        @functools.wraps(func)
+        def wrapped(name, inputs, *args, **kw):
+            merged = dict(_ARGSCOPE[-1].get(func.__name__, {}))
+            merged.update(kw)
+            with variable_scope(name):
+                return func(inputs, *args, **merged)
+        return wrapped
+    return deco
+
+
+def _conv_same_pads(size, k, s):
+    out = -(-size // s)
+    tot = max((out - 1) * s + k - size, 0)
+    return tot // 2, tot - tot // 2
+
+
+def _t(x):
+    return torch.from_numpy(np.ascontiguousarray(_np(x), dtype=np.float32))
+
+
+@layer_register()
+def Conv2D(x, out_channel, kernel_shape, padding="SAME", stride=1, W_init=None, b_init=None, nl=None, split=1,
+           use_bias=True, data_format="NHWC"):
+    assert data_format == "NCHW" and split == 1
+    cin = x.shape[1]
+    W = get_variable("W", (kernel_shape, kernel_shape, cin, out_channel))          # HWIO
+    xt = _t(x)
+    if padding.upper() == "SAME":
+        pt, pb = _conv_same_pads(xt.shape[2], kernel_shape, stride)
+        pl, pr = _conv_same_pads(xt.shape[3], kernel_shape, stride)
+        xt = F.pad(xt, (pl, pr, pt, pb))
+    b = get_variable("b", (out_channel,)) if use_bias else None
+    y = F.conv2d(xt, _t(W).permute(3, 2, 0, 1).contiguous(), None if b is None else _t(b), stride=stride)
+    return (nl or (lambda v, name=None: v))(T(y.numpy()), name="output")
+
+
+@layer_register()
+def MaxPooling(x, shape, stride=None, padding="VALID", data_format="NHWC"):
+    assert data_format == "NCHW" and padding.upper() == "VALID"
+    return T(F.max_pool2d(_t(x), shape, stride or shape).numpy())
+
+
+@layer_register()
+def BatchNorm(x, use_local_stat=None, decay=0.9, epsilon=1e-5, use_scale=True, use_bias=True, gamma_init=None,
+              data_format="NHWC", internal_update=False):
+    assert data_format == "NCHW" and use_local_stat is False
+    c = x.shape[1]
+    beta, gamma = get_variable("beta", (c,)), get_variable("gamma", (c,))
+    mean, var = get_variable("mean/EMA", (c,)), get_variable("variance/EMA", (c,))
+    return T(F.batch_norm(_t(x), _t(mean), _t(var), _t(gamma), _t(beta), False, 0.0, epsilon).numpy())
+
+
+def BNReLU(x, name=None):
+    return T(np.maximum(_np(BatchNorm("bn", x)), np.float32(0)))
+
+
+@layer_register()
+def FullyConnected(x, out_dim, W_init=None, b_init=None, nl=None, use_bias=True):
+    a = _np(x).reshape(len(_np(x)), -1)
+    W, b = get_variable("W", (a.shape[1], out_dim)), get_variable("b", (out_dim,))
+    y = (_t(T(a)) @ _t(W) + _t(b)).numpy() if len(a) else np.zeros((0, out_dim), np.float32)
+    return T(y)
+
+
+@layer_register()
+def GlobalAvgPooling(x, data_format="NHWC"):
+    assert data_format == "NCHW"
+    return T(_np(x).mean(axis=(2, 3), dtype=np.float32))
+
+
+@layer_register()
+def Deconv2D(x, *a, **k):
+    raise NotImplementedError("mask head is off in --forward (train.py:636-637)")
+
+
+class _Anything(types.ModuleType):
+    """Import stub: any attribute is a harmless callable / base class (cv2, pycocotools, tensorpack utilities ...)."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        v = type(name, (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, *a, **k: None})
+        setattr(self, name, v)
+        return v
+
+
+STUB_ROOTS = ("tensorpack", "cv2", "pycocotools", "termcolor", "tabulate", "tqdm", "zmq", "msgpack_numpy", "google")
+
+
+class _StubFinder:
+    """Any not-yet-registered submodule of the stubbed third-party roots imports as an ``_Anything`` package."""
+
+    @staticmethod
+    def find_spec(name, path=None, target=None):
+        import importlib.machinery
+        if name.split(".")[0] in STUB_ROOTS:
+            class _Loader:
+                @staticmethod
+                def create_module(spec):
+                    m = _Anything(spec.name)
+                    m.__path__ = []
+                    return m
+
+                @staticmethod
+                def exec_module(module):
+                    pass
+            return importlib.machinery.ModuleSpec(name, _Loader(), is_package=True)
+        return None
+
+
+def install(is_training: bool = False):
+    """Register the stand-ins in sys.modules (before importing the reference's modules)."""
+    tf = _tf_module()
+    mods = {"tensorflow": tf, "tensorflow.nn": tf.nn, "tensorflow.image": tf.image}
+    tp = _Anything("tensorpack")
+    names = ["tensorpack", "tensorpack.tfutils", "tensorpack.tfutils.summary", "tensorpack.tfutils.argscope",
+             "tensorpack.tfutils.scope_utils", "tensorpack.tfutils.common", "tensorpack.tfutils.tower", "tensorpack.models",
+             "tensorpack.utils", "tensorpack.utils.argtools", "tensorpack.utils.utils", "tensorpack.utils.viz",
+             "tensorpack.utils.gpu", "tensorpack.dataflow", "tensorpack.dataflow.imgaug", "tensorpack.dataflow.imgaug.transform",
+             "tensorpack.predict", "tensorpack.train", "tensorpack.callbacks", "tensorpack.graph_builder",
+             "tensorpack.graph_builder.model_desc", "tensorpack.input_source"]
+    for n in names:
+        mods[n] = tp if n == "tensorpack" else _Anything(n)
+    ident_deco = lambda *a, **k: (lambda f: f)                                     # noqa: E731
+    mods["tensorpack.tfutils"].get_current_tower_context = lambda: types.SimpleNamespace(is_training=is_training)
+    mods["tensorpack.tfutils.summary"].add_moving_summary = lambda *a, **k: None
+    mods["tensorpack.tfutils.argscope"].argscope = argscope
+    mods["tensorpack.tfutils.argscope"].get_arg_scope = get_arg_scope
+    mods["tensorpack.tfutils.scope_utils"].under_name_scope = ident_deco
+    mods["tensorpack.tfutils.scope_utils"].auto_reuse_variable_scope = lambda f: f
+    mods["tensorpack.utils.argtools"].memoized = lambda f: functools.lru_cache(maxsize=None)(f)
+    mods["tensorpack.utils.argtools"].log_once = lambda *a, **k: None
+    m = mods["tensorpack.models"]
+    m.Conv2D, m.MaxPooling, m.BatchNorm, m.BNReLU, m.FullyConnected = Conv2D, MaxPooling, BatchNorm, BNReLU, FullyConnected
+    m.GlobalAvgPooling, m.Deconv2D, m.layer_register = GlobalAvgPooling, Deconv2D, layer_register
+
+    class TransformAugmentorBase:                       # dataflow/imgaug/transform.py: _init(locals()) sets attributes
+        def _init(self, params=None):
+            for k, v in (params or {}).items():
+                if k != "self" and not k.startswith("_"):
+                    setattr(self, k, v)
+
+        def augment(self, img):                         # resizes with cv2 in the original: only the SHAPE survives here
+            t = self._get_augment_params(img)
+            return np.zeros((t.newh, t.neww) + img.shape[2:], img.dtype)
+
+    class ResizeTransform:
+        def __init__(self, h, w, newh, neww, interp):
+            self.h, self.w, self.newh, self.neww, self.interp = h, w, newh, neww, interp
+    tr = mods["tensorpack.dataflow.imgaug.transform"]
+    tr.TransformAugmentorBase, tr.ResizeTransform = TransformAugmentorBase, ResizeTransform
+    mods["tensorpack.dataflow.imgaug"].transform = tr
+    mods["tensorpack.dataflow"].imgaug = mods["tensorpack.dataflow.imgaug"]
+    for n in ("cv2", "pycocotools", "pycocotools.mask", "pycocotools.coco", "pycocotools.cocoeval", "scipy.misc", "tqdm",
+              "zmq", "termcolor", "tabulate", "msgpack_numpy"):
+        if n not in sys.modules or n == "scipy.misc":
+            mods[n] = _Anything(n)
+    mods["pycocotools"].mask = mods["pycocotools.mask"]
+    mods["cv2"].INTER_LINEAR = 1
+    # names train.py takes from `from tensorpack import *`
+    tp.ModelDesc = type("ModelDesc", (), {})
+    tp.InputDesc = lambda *a, **k: None
+    tp.Callback = type("Callback", (), {})
+    tp.get_current_tower_context = mods["tensorpack.tfutils"].get_current_tower_context
+    tp.__all__ = ["ModelDesc", "InputDesc", "Callback", "get_current_tower_context"]
+    for m_ in mods.values():
+        if isinstance(m_, _Anything):
+            m_.__path__ = []
+    for n, m_ in mods.items():                          # `import a.b.c as x` walks attributes of the parents
+        if "." in n and n.rsplit(".", 1)[0] in mods:
+            setattr(mods[n.rsplit(".", 1)[0]], n.rsplit(".", 1)[1], m_)
+    sys.modules.update(mods)
+    sys.meta_path.insert(0, _StubFinder)
+    for alias in ("float", "int", "bool"):             # numpy < 1.20 spellings the reference uses (data.py:49, BoundingBox.py:17)
+        if not hasattr(np, alias):
+            setattr(np, alias, {"float": float, "int": int, "bool": bool}[alias])
+    return tf

@@ -20,8 +20,6 @@ torch.save(PO.synth_weights(0), "weights/general.pt"); torch.save(PO.synth_weigh
 torch.save(RO.synth_weights(0), "weights/refine.pt"); torch.save(QO.synth_weights(0), "weights/reid.pt")
 os.makedirs("code/ReID_net/configs")
 json.dump({"model": "Re-ID", "load": os.path.abspath("weights/reid.pt")}, open("code/ReID_net/configs/run", "w"))
-from premvos_amd import run_pipeline
-import premvos_amd.run_pipeline as rp
 # time each stage by running the pipeline and watching directory creation order through a patched print
 t0 = time.time()
 stamps = {}
