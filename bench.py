@@ -11,8 +11,13 @@ resident in HBM when the clock starts:
     +  refinement_net on P = 20 boxes per frame                                  (2.42 TFLOP/frame)
 Refinement boxes are the seeded synthetic boxes SURVEY.md 8(d) prescribes (random-weight proposals are
 meaningless); the two proposal passes still run completely (100 RoIs each) inside the timed region.
-Each rank owns its own frames (no data-path collective); per step the results (flow, masks, conf, boxes) are
-gathered to rank 0 -- the merge rank -- with RCCL, inside the timed region.  Rank 0 prints ONE JSON line.
+Each rank owns its own frames (no data-path collective); per step every rank's results (flow, bit-packed masks, conf,
+boxes) go to rank 0 -- the merge rank -- in ONE RCCL gather of one fixed-size buffer (premvos_amd.parallel.ResultExchange),
+inside the timed region.  Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment launches its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one process per GPU) and fails
+loudly when the node has fewer than N GPUs.
 """
 from __future__ import annotations
 
@@ -54,58 +59,63 @@ def parse():
 
 def synth_frames(batch: int, rank: int):
     """Smooth seeded noise frames + sub-pixel translated successors, uint8 RGB [B,H,W,3]."""
-    from oracle import pwc_oracle as O
-    a, b = [], []
-    for i in range(batch):
-        pair = O.synth_frame_pair(H, W + 2, seed=1234 + 100 * rank + i, shift=(1.5 + 0.25 * i, -0.75))
-        fr = (pair[0, :, :, :W].permute(1, 2, 0) * 255).round().to(torch.uint8)       # [H,W,6]
-        a.append(fr[..., :3])
-        b.append(fr[..., 3:])
-    return torch.stack(a).contiguous(), torch.stack(b).contiguous()
+    from premvos_amd import synth
+    return synth.video_frames(batch, H, W, rank)
 
 
 def synth_boxes(batch: int, rank: int) -> torch.Tensor:
     """[B,P,4] (y0,x0,y1,x1): seeded uniform boxes with w,h in [40,400] clipped to the frame."""
-    rng = np.random.default_rng(4321 + rank)
-    wh = rng.uniform(40, 400, (batch, P_BOXES, 2))
-    wh = np.minimum(wh, [W, H])
-    xy = rng.uniform(0, 1, (batch, P_BOXES, 2)) * (np.array([W, H]) - wh)
-    return torch.tensor(np.stack([xy[..., 1], xy[..., 0], xy[..., 1] + wh[..., 1], xy[..., 0] + wh[..., 0]], -1),
-                        dtype=torch.float32)
+    from premvos_amd import synth
+    return synth.boxes(batch, P_BOXES, H, W, rank)
 
 
 def cpu_baseline():
-    """The oracle (plain-PyTorch restatement of the reference: kind='port') timed on the host cores on a bounded
-    sample of the same per-frame workload, scaled to one frame."""
+    """The oracle (plain-PyTorch restatement of the reference: kind='port') timed on the host cores on a bounded sample
+    of the same per-frame workload, scaled to one frame.  Protocol: per stage 3 warm-up + 10 timed runs, median.
+    This leg -- and only this leg -- imports oracle/ (the checker doubles as the CPU baseline)."""
     from oracle import proposal_oracle as PO
     from oracle import pwc_oracle as O
     from oracle import refinement_oracle as RO
     ncpu = os.cpu_count() or 1
     cores = min(ncpu, 32)          # torch-CPU convs collapse when oversubscribed (256 threads: 131 s per PWC pair)
     torch.set_num_threads(cores)
-    fa, fb = synth_frames(1, 0)
+    WARM, TIMED = 3, 10
+
+    def median_time(fn):
+        for _ in range(WARM):
+            fn()
+        ts = []
+        for _ in range(TIMED):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return sorted(ts)[len(ts) // 2]
+
+    fa, _ = synth_frames(1, 0)
     with torch.no_grad():
         sd = O.synth_state_dict(0)
         x = O.synth_frame_pair(512, 896)
-        O.pwc_forward(sd, x)
-        t = time.perf_counter(); O.pwc_forward(sd, x); t_flow = time.perf_counter() - t
+        t_flow = median_time(lambda: O.pwc_forward(sd, x))
         w = PO.synth_weights(0)
         img = np.ascontiguousarray(fa[0].numpy()[:, :, ::-1])
-        t = time.perf_counter(); PO.detect_one_image(w, img); t_prop = time.perf_counter() - t
+        t_prop = median_time(lambda: PO.detect_one_image(w, img))
         rw = RO.synth_weights(0)
         boxes = synth_boxes(1, 0)[0].numpy()
-        nb = 3
-        t = time.perf_counter()
-        for i in range(nb):
-            net_in, crop = RO.make_input(fa[0].numpy(), boxes[i])
+        frame = fa[0].numpy()
+        state = {"i": 0}
+
+        def one_box():
+            b = boxes[state["i"] % len(boxes)]
+            state["i"] += 1
+            net_in, crop = RO.make_input(frame, b)
             RO.output_layer(RO.deeplab_logits(rw, net_in), crop, H, W)
-        t_box = (time.perf_counter() - t) / nb
+        t_box = median_time(one_box)
     per_frame = t_flow + 2 * t_prop + P_BOXES * t_box
     return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 PWC-Net pair @512x896 ({t_flow:.2f} s) + 1 proposal_net pass @749x1333/100 RoIs ({t_prop:.2f} s) "
-                      f"+ {nb} refinement boxes @385x385 ({t_box:.2f} s/box), fp32 oracle/*.py on torch "
-                      f"{torch.__version__} CPU with {cores} of {ncpu} host threads; scaled to a frame as "
-                      f"flow + 2*proposal + {P_BOXES}*box = {per_frame:.1f} s"}
+            "sample": f"median of {TIMED} timed runs after {WARM} warm-ups per stage: 1 PWC-Net pair @512x896 ({t_flow:.2f} s), "
+                      f"1 proposal_net pass @749x1333/100 RoIs ({t_prop:.2f} s), 1 refinement box @385x385 ({t_box:.2f} s), "
+                      f"fp32 oracle/*.py on torch {torch.__version__} CPU with {cores} of {ncpu} host threads; scaled to a frame "
+                      f"as flow + 2*proposal + {P_BOXES}*box = {per_frame:.1f} s"}
 
 
 def roofline(pipe, batch):
@@ -135,12 +145,16 @@ def roofline(pipe, batch):
         a = per_stage.setdefault(st, [0.0, 0.0])
         a[0] += f
         a[1] += t * m
-    traffic = None      # HBM bytes per launch from the PMC passes (profiles/r01_conv_hbm_traffic.json: method + corrections)
+    # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure is the one the round's
+    # rocprofv3 --pmc passes over this very command produced (tools/profile_round.sh -> profiles/rNN_conv_hbm_traffic.json,
+    # method + gfx950 corrections inside); `traffic_source` says so.  null when no such file exists for this batch size.
+    traffic, traffic_source = None, None
     import glob
     tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_hbm_traffic.json")))      # newest round last
     if batch == 16 and tfs:        # the PMC passes of tools/profile_round.sh run the default batch
         try:
             traffic = round(json.load(open(tfs[-1]))["hbm_bytes_per_launch"])
+            traffic_source = "profiles/" + os.path.basename(tfs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a previous run of this command, not this run)"
         except Exception:
             traffic = None
     alg_bytes = sum(it[4] for it in items)
@@ -157,11 +171,51 @@ def roofline(pipe, batch):
     ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel (every dense conv of the three nets; the seven 1-2 channel heads run "
                                        "on conv_smalln_kernel and are counted with their algorithmic FLOPs)", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": round(alg_bytes / nl), "mfma_ceiling_measured": round(ceiling, 1),
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),
             "conv_ms_per_step": round(ms, 3), "conv_ms_each_layer_once": round(sum(tot), 3),
             "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed: start the N ranks ourselves, one process per GPU."""
+    import socket
+    import subprocess
+    backend = os.environ.get("PREMVOS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and backend == "nccl":
+        raise SystemExit(f"bench.py --gpus {a.gpus}: this node exposes {ndev} GPU(s); refusing to measure fewer GPUs than asked "
+                         f"(RCCL needs one device per rank)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def shared_tune_cache(rank: int, world: int):
+    """All ranks must freeze the SAME conv configurations (a different tile / k-split changes the fp32 summation order, so
+    ranks would disagree in the last bits): rank 0 tunes while building and warming its pipeline, the others wait and load its
+    choices.  Returns a callable rank 0 invokes once its plans exist."""
+    import tempfile
+    from premvos_amd import ops
+    path = os.environ.get("PREMVOS_TUNE_CACHE")
+    if not path:
+        path = os.path.join(tempfile.gettempdir(), f"premvos_tune_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.json")
+        os.environ["PREMVOS_TUNE_CACHE"] = path
+    if rank != 0:
+        dist.barrier()               # rank 0 has written the cache
+        ops.load_tune_cache(path)
+        os.environ["PREMVOS_AUTOTUNE_FROZEN"] = "1"      # a signature rank 0 did not see is an error, not a private re-tune
+        return lambda: None
+
+    def publish():
+        ops.save_tune_cache(path)
+        dist.barrier()
+    return publish
 
 
 def main():
@@ -170,56 +224,57 @@ def main():
     if a.frame == "1080p":
         H, W = 1080, 1920
         a.no_cpu_baseline = True            # the CPU sample is defined on the metric's 480p workload
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}")
     force_dist = os.environ.get("PREMVOS_BENCH_FORCE_DIST") == "1"     # exercise the gather path on one GPU
-    if world > 1 or force_dist:
+    use_dist = world > 1 or force_dist
+    backend = os.environ.get("PREMVOS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s) visible: one device per rank is required")
+    dev = torch.device("cuda", local % max(ndev, 1))
+    torch.cuda.set_device(dev)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
         # RCCL ("nccl") is the product path; PREMVOS_BENCH_BACKEND=gloo lets the multi-rank logic be exercised by several
         # processes sharing ONE GPU (RCCL refuses two ranks on the same device)
-        dist.init_process_group(os.environ.get("PREMVOS_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    assert world == a.gpus or world == 1, (world, a.gpus)
-    dev = torch.device("cuda", local if local < torch.cuda.device_count() else 0)
-    torch.cuda.set_device(dev)
+        import datetime
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
 
-    # oracle modules are used here ONLY as generators of synthetic weights / frames (no checkpoint, no DAVIS)
-    from oracle import proposal_oracle as PO
-    from oracle import pwc_oracle as O
-    from oracle import refinement_oracle as RO
+    from premvos_amd import synth
+    from premvos_amd.parallel import ResultExchange
     from premvos_amd.pipeline import FramePipeline
 
     B = a.batch
     prec = a.precision
     flow_prec = "fp32" if prec.startswith("mixed") else prec
     net_prec = prec.split("-")[1] if prec.startswith("mixed") else prec
-    pipe = FramePipeline(O.synth_state_dict(0), PO.synth_weights(0), PO.synth_weights(1), RO.synth_weights(0),
-                         batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec, flow_precision=flow_prec)
+    publish = shared_tune_cache(rank, world) if world > 1 else (lambda: None)
+    pipe = FramePipeline(synth.pwc_state_dict(0), synth.proposal_weights(0), synth.proposal_weights(1),
+                         synth.refinement_weights(0), batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec,
+                         flow_precision=flow_prec)
     fa, fb = synth_frames(B, rank)
     fa, fb = fa.to(dev), fb.to(dev)
     boxes = synth_boxes(B, rank).to(dev)
-
-    gbuf = None
-    use_dist = world > 1 or force_dist
-    if use_dist and rank == 0:
-        gbuf = {"flow": [torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) for _ in range(world)],
-                "masks": [torch.empty((B, P_BOXES, H, W), dtype=torch.uint8, device=dev) for _ in range(world)],
-                "small": [torch.empty((B, 2 * 20 * 5 + P_BOXES + 2), dtype=torch.float32, device=dev) for _ in range(world)]}
+    xchg = ResultExchange(B, H, W, P_BOXES, dev) if use_dist else None
 
     def step():
         r = pipe.step(fa, fb, boxes)
-        if use_dist:        # the single exchange of the path: results -> merge rank
-            small = torch.cat([r["general_boxes"].reshape(B, -1), r["general_probs"], r["specific_boxes"].reshape(B, -1),
-                               r["specific_probs"], r["conf"], r["general_count"].view(B, 1).float(),
-                               r["specific_count"].view(B, 1).float()], 1).contiguous()
-            dist.gather(r["flow"], gbuf["flow"] if rank == 0 else None, dst=0)
-            dist.gather(r["masks"], gbuf["masks"] if rank == 0 else None, dst=0)
-            dist.gather(small, gbuf["small"] if rank == 0 else None, dst=0)
+        if use_dist:        # the single exchange of the path: ONE gather of one packed buffer -> merge rank
+            xchg.exchange(r)
         return r
 
+    if world > 1 and rank == 0:
+        pipe.step(fa, fb, boxes)          # builds + tunes every plan (no collective: the other ranks wait in publish())
+        torch.cuda.synchronize()
+    publish()
     for _ in range(a.warmup):
         step()
     if use_dist:
@@ -234,7 +289,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -257,7 +312,9 @@ def main():
                                + "results (flow, masks, conf, boxes) left in HBM",
                    "frames_per_step_per_gpu": B, "stages": ["flow", "proposal_general", "proposal_specific", "refinement"],
                    "gflop_per_frame": 2420 if a.frame == "480p" else 3018,
-                   "parallelism": f"frames sharded over {world} GPU(s); RCCL gather of results to rank 0 per step"},
+                   "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; ONE "
+                                  f"{'RCCL' if backend == 'nccl' else backend} gather per step of one packed buffer per rank "
+                                  f"({xchg.nbytes if xchg else 0} B: flow f32, masks bit-packed, boxes/scores/conf) to rank 0"},
     }
     if rank == 0:
         if not a.no_roofline:

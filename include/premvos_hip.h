@@ -300,6 +300,13 @@ int64_t premvos_rle_workspace_bytes(int32_t n, int32_t h, int32_t w);
 int premvos_rle_boundaries_u8(const uint8_t* masks, int32_t n, int32_t h, int32_t w, int32_t* positions,
                               int32_t capacity, int32_t* nruns, void* workspace, void* stream);
 
+/* Masks on the wire (ONE gather of fixed-size buffers per chunk to the merge rank, masks bit-packed): n mask
+ * bytes (nonzero = foreground) -> ceil(n/8) bytes, bit k of byte i = masks[8i + k] != 0; and back to {0,1} bytes.  Replaces the
+ * reference's hand-over through per-frame JSON files (refinement_net/forwarding/FewShotSegmentationForwarder.py:151-155 read
+ * back by MergeTrack/merge_functions.py:38-76). */
+int premvos_mask_pack_bits_u8(const uint8_t* masks, int64_t n, uint8_t* bits, void* stream);
+int premvos_mask_unpack_bits_u8(const uint8_t* bits, int64_t n, uint8_t* masks, void* stream);
+
 /* Host-side utility (no GPU work): COCO rleToString of `n` run lengths into `out` (capacity `cap` bytes); returns the
  * length or -1 -- the "counts" string of every mask the refinement / merge stages write
  * (forwarding/FewShotSegmentationForwarder.py:141-142). */

@@ -71,6 +71,8 @@ SIGNATURES = {
     "premvos_scale_shift_relu_f32": [_vp, _i32, C.c_int64, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "premvos_mask_warp_u8": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
     "premvos_mask_overlap_u8": [_vp, _i32, _vp, _i32, C.c_int64, _vp, _vp, _vp, _vp],
+    "premvos_mask_pack_bits_u8": [_vp, C.c_int64, _vp, _vp],
+    "premvos_mask_unpack_bits_u8": [_vp, C.c_int64, _vp, _vp],
     "premvos_rle_boundaries_u8": [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "premvos_frcnn_tail_f32": [_vp, _i32, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32,
                                _f32, _vp, _vp, _vp, _vp, _vp],

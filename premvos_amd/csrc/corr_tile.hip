@@ -11,9 +11,9 @@
 //   * one thread owns one pixel: its f1 channels sit in registers, its 81 sums in 81 accumulators; per chunk it reads
 //     81 x 4 float4 from LDS for 81 x 16 FMAs (one LDS read per 4 FMAs -- the LDS pipe, not HBM, would bound a
 //     naive "one lane per displacement" mapping);
-//   * the sums leave through LDS so that the 81 floats of a pixel go out as one contiguous run (two passes of 45 / 36
-//     displacement rows reuse the f2 tile's LDS); LeakyReLU(0.1) (PWCNet.py:198) and the torch.cat copy of c1
-//     (PWCNet.py:213) are fused as before.
+//   * the sums leave through LDS so that the 81 floats of a pixel go out as one contiguous run in 16-byte pieces (two
+//     passes of 44 / 37 floats reuse the f2 tile's LDS); LeakyReLU(0.1) (PWCNet.py:198) is fused, and the torch.cat copy
+//     of c1 (PWCNet.py:213) is written from the registers that hold the f1 pixel.
 //   * WARP: f2 is not read but produced on the fly by the backward bilinear warp of image-2 features by the
 //     up-sampled flow (PWCDCNet.warp, PWCNet.py:140-176: same float sequence as warp_kernel in flow_ops.hip), so the
 //     warped feature map never exists in HBM.
@@ -31,8 +31,6 @@ constexpr int HALO_H = T_H + 2 * MD, HALO_W = T_W + 2 * MD;
 constexpr int CCH = 16;            // channels per LDS chunk
 constexpr int PSTR = CCH + 4;      // padded pixel stride (floats)
 constexpr int LDS_FLOATS = HALO_H * HALO_W * PSTR;   // 12 800 floats = 51 200 B -> 3 workgroups per CU
-constexpr int ROWS_A = 5;          // displacement rows of the first output pass (5 x 9 = 45 floats per pixel)
-static_assert(256 * ROWS_A * D <= LDS_FLOATS, "output staging must fit the f2 tile's LDS");
 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // 16 bytes at 4-byte alignment
 
@@ -94,7 +92,11 @@ __global__ __launch_bounds__(256, 3) void corr81_tile_kernel(const float* __rest
         const float* fl = flow + pix * flow_ps;
         v[j] = premvos::warp_sample4(f2 + img * f2_ps + ch, f2_ps, fl[0] * fscale, fl[1] * fscale, gx, gy, h, w);
       } else {
+#ifdef CORR_DBG_NO_LOAD
+        v[j] = make_float4((float)pix, (float)ch, 0.f, 1.f);
+#else
         v[j] = *reinterpret_cast<const float4*>(f2 + pix * f2_ps + ch);
+#endif
       }
     }
     float4 a[CCH / 4];
@@ -116,6 +118,10 @@ __global__ __launch_bounds__(256, 3) void corr81_tile_kernel(const float* __rest
       if (copy_f1 && ok) *reinterpret_cast<f4u*>(out + (img + (long)y * w + x) * out_ps + D * D + k0 + q * 4) = f4u{a[q].x, a[q].y, a[q].z, a[q].w};
     }
     __syncthreads();
+#ifdef CORR_DBG_NO_COMPUTE
+    acc[0] += lds[tid] + a[0].x;
+    continue;
+#endif
     // ---- 81 displacements x 16 channels ------------------------------------------------------
     const float* base = &lds[(ty * HALO_W + tx) * PSTR];
     // per (displacement row, 4-channel group): 9 independent LDS reads in flight, then 9 independent FMA chains
@@ -144,36 +150,83 @@ __global__ __launch_bounds__(256, 3) void corr81_tile_kernel(const float* __rest
   const bool pow2 = (c & (c - 1)) == 0;
   const float rc = 1.0f / fc;
   const int wave = tid >> 6, lane = tid & 63;
-  auto stage = [&](auto e0_, auto ne_) {          // this thread's sums e0 .. e0+ne -> lds[pixel][ne]
-    constexpr int e0 = decltype(e0_)::value, ne = decltype(ne_)::value;
+  const bool wide = ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) && (out_ps & 3) == 0;
+  auto mean_act = [&](float sum) {
+    const float v = pow2 ? sum * rc : sum / fc;
+    return v < 0.f ? v * slope : v;
+  };
+  // The 81 sums of a pixel leave through LDS so that the pixel's run goes out in 16-byte pieces (the run starts 16-byte
+  // aligned when `wide`): pass A = elements [0,44) = 11 float4 per pixel, LDS row pitch 44 (the rows tile LDS linearly:
+  // conflict-free b128 writes and reads); pass B = elements [44,81) = 9 float4 + 1 float, row pitch 40.
+  constexpr int NA = 44, NB = D * D - NA, PB = 40;
+  static_assert(NA % 4 == 0 && NB == 37 && 256 * NA <= LDS_FLOATS && 256 * PB <= LDS_FLOATS, "output staging layout");
+  auto stage_a = [&]() {
     if (pow2) {
 #pragma unroll
-      for (int e = 0; e < ne; ++e) {
-        const float v = acc[e0 + e] * rc;
-        lds[tid * ne + e] = v < 0.f ? v * slope : v;
-      }
+      for (int j = 0; j < NA / 4; ++j)
+        *reinterpret_cast<float4*>(&lds[tid * NA + 4 * j]) = make_float4(mean_act(acc[4 * j]), mean_act(acc[4 * j + 1]), mean_act(acc[4 * j + 2]), mean_act(acc[4 * j + 3]));
     } else {
 #pragma unroll
-      for (int e = 0; e < ne; ++e) {
-        const float v = acc[e0 + e] / fc;
-        lds[tid * ne + e] = v < 0.f ? v * slope : v;
+      for (int j = 0; j < NA / 4; ++j)
+        *reinterpret_cast<float4*>(&lds[tid * NA + 4 * j]) = make_float4(mean_act(acc[4 * j]), mean_act(acc[4 * j + 1]), mean_act(acc[4 * j + 2]), mean_act(acc[4 * j + 3]));
+    }
+  };
+  auto stage_b = [&]() {
+    if (pow2) {
+#pragma unroll
+      for (int j = 0; j < NB / 4; ++j)
+        *reinterpret_cast<float4*>(&lds[tid * PB + 4 * j]) = make_float4(mean_act(acc[NA + 4 * j]), mean_act(acc[NA + 4 * j + 1]), mean_act(acc[NA + 4 * j + 2]), mean_act(acc[NA + 4 * j + 3]));
+      lds[tid * PB + NB - 1] = mean_act(acc[D * D - 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB / 4; ++j)
+        *reinterpret_cast<float4*>(&lds[tid * PB + 4 * j]) = make_float4(mean_act(acc[NA + 4 * j]), mean_act(acc[NA + 4 * j + 1]), mean_act(acc[NA + 4 * j + 2]), mean_act(acc[NA + 4 * j + 3]));
+      lds[tid * PB + NB - 1] = mean_act(acc[D * D - 1]);
+    }
+  };
+  auto pix_of = [&](int p, bool& ok) {
+    const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+    ok = yy < h && xx < w;
+    return (img + (long)yy * w + xx) * out_ps;
+  };
+  auto flush = [&](int e0, int n4, int pitch, int tail) {     // n4 float4 (+ `tail` single floats) per pixel row of LDS
+    __syncthreads();
+    if (wide) {
+      for (int u = tid; u < 256 * n4; u += 256) {
+        const int p = u / n4, j = u - p * n4;
+        bool ok;
+        const long o = pix_of(p, ok);
+        if (ok) *reinterpret_cast<float4*>(out + o + e0 + 4 * j) = *reinterpret_cast<const float4*>(&lds[p * pitch + 4 * j]);
+      }
+      if (tail) {
+        bool ok;
+        const long o = pix_of(tid, ok);
+        if (ok) out[o + e0 + 4 * n4] = lds[tid * pitch + 4 * n4];
+      }
+    } else {                                          // unaligned destination: one wave per pixel run, 4-byte stores
+      const int ne = 4 * n4 + tail;
+      for (int p = wave; p < T_H * T_W; p += 4) {
+        bool ok;
+        const long o = pix_of(p, ok);
+        if (ok && lane < ne) out[o + e0 + lane] = lds[p * pitch + lane];
       }
     }
   };
-  auto flush = [&](int e0, int ne) {          // lds[pixel][ne] -> out[pixel][e0 .. e0+ne): one wave per pixel run
-    __syncthreads();
-    for (int p = wave; p < T_H * T_W; p += 4) {          // wave-uniform: the pixel arithmetic runs on the scalar unit
-      const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
-      if (yy < h && xx < w && lane < ne) out[(img + (long)yy * w + xx) * out_ps + e0 + lane] = lds[p * ne + lane];
-    }
-  };
+#ifdef CORR_DBG_NO_OUTPUT
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) t += acc[e];
+    if (t == 1234.5f) out[0] = t;
+    return;
+  }
+#endif
   __syncthreads();                                   // f2 tile no longer needed
-  using std::integral_constant;
-  stage(integral_constant<int, 0>{}, integral_constant<int, ROWS_A * D>{});
-  flush(0, ROWS_A * D);
+  stage_a();
+  flush(0, NA / 4, NA, 0);
   __syncthreads();
-  stage(integral_constant<int, ROWS_A * D>{}, integral_constant<int, (D - ROWS_A) * D>{});
-  flush(ROWS_A * D, (D - ROWS_A) * D);
+  stage_b();
+  flush(NA, NB / 4, PB, 1);
 }
 
 }  // namespace
@@ -192,3 +245,11 @@ int corr81_tile(const float* f1, int f1_ps, const float* f2, int f2_ps, const fl
   return check_launch("corr81_tile");
 }
 }  // namespace premvos
+
+#ifdef CORR_DBG_ENTRY      // stand-alone timing builds of tools/dev/corr_variants.sh (phases compiled out compute garbage)
+namespace premvos { thread_local char g_err[512] = ""; }
+extern "C" int corr_dbg(const float* f1, int f1_ps, const float* f2, int f2_ps, float* out, int out_ps, int n, int h, int w, int c,
+                        void* stream) {
+  return premvos::corr81_tile(f1, f1_ps, f2, f2_ps, nullptr, 0, 0.f, out, out_ps, n, h, w, c, 0.1f, 1, static_cast<hipStream_t>(stream));
+}
+#endif

@@ -167,7 +167,7 @@ class _Plan:
             self.run(steps)     # warm-up outside capture
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads (IO lanes) keep using the GPU
             self.run(steps)
         if steps is None:
             self.graph = g

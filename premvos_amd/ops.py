@@ -202,6 +202,9 @@ def assign_workspace(descs, device="cuda") -> Optional[torch.Tensor]:
 
 
 _TUNE_CACHE: dict = {}
+# Building a launch plan (buffers, autotuning on the real buffers, HIP-graph capture) is serialised across host threads: the
+# streaming driver and the IO lanes of the stage drivers run several nets from several threads.
+BUILD_LOCK = __import__("threading").RLock()
 
 
 def _sig(d: ConvDesc):
@@ -246,6 +249,24 @@ def _candidates(d: ConvDesc):
     return out
 
 
+def load_tune_cache(path: str) -> int:
+    """Merge a saved table of tuned configurations (signature -> choice) into this process."""
+    import json
+    with open(path) as f:
+        _TUNE_CACHE.update({tuple(k): tuple(v) + (0,) * (5 - len(v)) for k, v in json.load(f)})
+    return len(_TUNE_CACHE)
+
+
+def save_tune_cache(path: str) -> None:
+    """Atomic (temp file + rename): several processes may read the table while one replaces it."""
+    import json
+    import os
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        json.dump([[list(k), list(v)] for k, v in _TUNE_CACHE.items()], f)
+    os.replace(tmp, path)
+
+
 def autotune(descs, device="cuda", reps: int = 4):
     """cuDNN-find style: per distinct layer signature time the legal (tile, stage depth, k-split) configurations of the
     conv kernel on the real buffers and freeze the fastest into the descriptor.  The heuristics in the library are the
@@ -259,9 +280,11 @@ def autotune(descs, device="cuda", reps: int = 4):
     stream = _lib.current_stream()
     cache_file = os.environ.get("PREMVOS_TUNE_CACHE")        # optional: reuse a previous process's choices
     if cache_file and not _TUNE_CACHE and os.path.exists(cache_file):
-        import json
-        _TUNE_CACHE.update({tuple(k): tuple(v) + (0,) * (5 - len(v)) for k, v in json.load(open(cache_file))})
+        load_tune_cache(cache_file)
     todo = [d for d in descs if _sig(d) not in _TUNE_CACHE]
+    if todo and os.environ.get("PREMVOS_AUTOTUNE_FROZEN") == "1":
+        # ranks > 0 of a multi-GPU job run rank 0's choices: tuning privately would give ranks different summation orders
+        raise _lib.PremvosError(f"{len(todo)} conv signature(s) are missing from the shared tune table {cache_file}")
     if todo:
         need = 0
         for d in todo:
@@ -292,9 +315,8 @@ def autotune(descs, device="cuda", reps: int = 4):
                     best, best_t = cand, t
             _TUNE_CACHE[sig] = best
             d.workspace, d.workspace_bytes = None, 0
-        if cache_file:
-            import json
-            json.dump([[list(k), list(v)] for k, v in _TUNE_CACHE.items()], open(cache_file, "w"))
+        if cache_file and os.environ.get("RANK", "0") == "0":
+            save_tune_cache(cache_file)
     for d in descs:
         d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = _TUNE_CACHE[_sig(d)]
 

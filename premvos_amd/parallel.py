@@ -55,3 +55,96 @@ def gather_padded(local: torch.Tensor, n_valid: int, capacity: int, dst: int = 0
     if rank != dst:
         return None
     return [b[:int(c.item())] for b, c in zip(bufs, cnts)]
+
+
+class ResultExchange:
+    """The one exchange of the path: every rank's per-step results go to the merge rank as ONE fixed-size byte buffer in
+    ONE gather -- flow [B,H,W,2] f32 | masks [B,P,H,W] bit-packed | boxes / scores / conf / counts f32.
+
+    ``pack_bits(masks_u8, out_bits_u8)`` / ``unpack_bits(bits_u8, out_masks_u8)`` default to the HIP kernels
+    (premvos_mask_pack_bits_u8 / premvos_mask_unpack_bits_u8); the CPU gloo tests inject numpy twins.  With the gloo backend
+    (CPU tests; several ranks sharing one GPU when exercising the logic by hand) the buffer is staged through the host.
+    """
+
+    SMALL_COLS_FIXED = 2 * 20 * 5 + 2          # general + specific: 20 boxes x (4 + prob), + the two detection counts
+
+    def __init__(self, batch: int, h: int, w: int, boxes_per_frame: int, device, dst: int = 0, group=None,
+                 pack_bits=None, unpack_bits=None):
+        self.B, self.H, self.W, self.P, self.dst, self.group = batch, h, w, boxes_per_frame, dst, group
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.flow_bytes = batch * h * w * 2 * 4
+        self.mask_bits = batch * boxes_per_frame * h * w
+        self.mask_bytes = (self.mask_bits + 7) // 8
+        self.small_cols = self.SMALL_COLS_FIXED + boxes_per_frame
+        self.off_mask = self.flow_bytes
+        self.off_small = (self.off_mask + self.mask_bytes + 15) // 16 * 16
+        self.nbytes = self.off_small + batch * self.small_cols * 4
+        self.packed = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        self.host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo" and self.device.type != "cpu"
+        gdev = torch.device("cpu") if self.host_staged else self.device
+        self.gathered = ([torch.zeros(self.nbytes, dtype=torch.uint8, device=gdev) for _ in range(self.world)]
+                         if self.rank == dst else None)
+        self._pack_bits, self._unpack_bits = pack_bits or _hip_pack_bits, unpack_bits or _hip_unpack_bits
+
+    def pack(self, r) -> torch.Tensor:
+        """r: the dict FramePipeline.step returns.  Fills and returns this rank's byte buffer."""
+        B = self.B
+        self.packed[:self.flow_bytes].view(torch.float32).view(B, self.H, self.W, 2).copy_(r["flow"])
+        self._pack_bits(r["masks"].contiguous().view(-1), self.packed[self.off_mask:self.off_mask + self.mask_bytes])
+        small = self.packed[self.off_small:].view(torch.float32).view(B, self.small_cols)
+        c = 0
+        for key, n in (("general_boxes", 80), ("general_probs", 20), ("specific_boxes", 80), ("specific_probs", 20),
+                       ("conf", self.P), ("general_count", 1), ("specific_count", 1)):
+            small[:, c:c + n].copy_(r[key].reshape(B, n))        # counts are stored as exact small floats
+            c += n
+        return self.packed
+
+    def exchange(self, r):
+        """pack + the single gather.  Returns the list of per-rank byte buffers on the merge rank, None elsewhere."""
+        buf = self.pack(r)
+        if self.world == 1 and not dist.is_initialized():
+            return [buf]
+        send = buf.cpu() if self.host_staged else buf
+        dist.gather(send, self.gathered if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        return self.gathered
+
+    def unpack(self, buf: torch.Tensor):
+        """One rank's byte buffer -> dict of tensors (masks as {0,1} bytes), on ``buf``'s device."""
+        B, P = self.B, self.P
+        flow = buf[:self.flow_bytes].view(torch.float32).view(B, self.H, self.W, 2)
+        masks = torch.empty(self.mask_bits, dtype=torch.uint8, device=buf.device)
+        self._unpack_bits(buf[self.off_mask:self.off_mask + self.mask_bytes], masks)
+        small = buf[self.off_small:].view(torch.float32).view(B, self.small_cols)
+        out = {"flow": flow, "masks": masks.view(B, P, self.H, self.W)}
+        c = 0
+        for key, n, shape in (("general_boxes", 80, (B, 20, 4)), ("general_probs", 20, (B, 20)), ("specific_boxes", 80, (B, 20, 4)),
+                              ("specific_probs", 20, (B, 20)), ("conf", P, (B, P)), ("general_count", 1, (B,)),
+                              ("specific_count", 1, (B,))):
+            out[key] = small[:, c:c + n].reshape(shape)
+            c += n
+        out["general_count"], out["specific_count"] = out["general_count"].to(torch.int32), out["specific_count"].to(torch.int32)
+        return out
+
+
+def _hip_pack_bits(masks: torch.Tensor, out: torch.Tensor):
+    from . import _lib
+    _lib.require_gpu()
+    assert masks.is_cuda and out.is_cuda and masks.dtype == torch.uint8 and out.numel() == (masks.numel() + 7) // 8
+    _lib.check(_lib.load().premvos_mask_pack_bits_u8(masks.data_ptr(), masks.numel(), out.data_ptr(), _lib.current_stream()),
+               "mask_pack_bits")
+
+
+def _hip_unpack_bits(bits: torch.Tensor, out: torch.Tensor):
+    from . import _lib
+    _lib.require_gpu()
+    if not bits.is_cuda:                       # host-staged (gloo) buffers are unpacked where the merge loop's GPU helpers live
+        bits = bits.cuda()
+        tmp = torch.empty(out.numel(), dtype=torch.uint8, device=bits.device)
+        _lib.check(_lib.load().premvos_mask_unpack_bits_u8(bits.data_ptr(), out.numel(), tmp.data_ptr(), _lib.current_stream()),
+                   "mask_unpack_bits")
+        out.copy_(tmp)
+        return
+    _lib.check(_lib.load().premvos_mask_unpack_bits_u8(bits.data_ptr(), out.numel(), out.data_ptr(), _lib.current_stream()),
+               "mask_unpack_bits")

@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, ops
 from .model import (RESNET_NUM_BLOCK, RESULTS_PER_IM, TEST_POST_NMS_TOPK, ProposalNet)
 
 SHORT_EDGE_SIZE, MAX_SIZE = 800, 1333      # config.py:64-65
@@ -75,6 +75,10 @@ class ProposalStage:
     def _prepare(self, h: int, w: int):
         if self._shape == (h, w):
             return
+        with ops.BUILD_LOCK:
+            self._prepare_locked(h, w)
+
+    def _prepare_locked(self, h: int, w: int):
         self.nh, self.nw = custom_resize_shape(h, w)
         self.scale = (self.nh * 1.0 / h + self.nw * 1.0 / w) / 2          # eval.py:78
         self.plan = self.net.plan(self.batch, self.nh, self.nw)
@@ -216,26 +220,39 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
         if not os.path.exists(out_fn):
             todo.append((fn, out_fn))
     batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "1")))     # measured: host decode dominates, 1 is fastest
-    n, i = 0, 0
-    while i < len(todo):
-        chunk = []
-        while i < len(todo) and len(chunk) < batch:
-            img = np.asarray(Image.open(todo[i][0]).convert("RGB"))[:, :, ::-1]     # cv2.imread gives BGR (train.py:500)
-            if chunk and img.shape != chunk[0][1].shape:
+    from .. import io_pipeline as iop
+
+    def load(job):
+        img = np.asarray(Image.open(job[0]).convert("RGB"))[:, :, ::-1]             # cv2.imread gives BGR (train.py:500)
+        return job[1], np.ascontiguousarray(img)
+
+    def dump(out_fn, res):
+        with open(out_fn, "w") as f:
+            json.dump(convert_results_to_json(res), f)
+
+    decoded = iop.prefetch(todo, load)            # JPEG decode runs ahead on a thread pool, JSON is written in the background
+    n, held = 0, None
+    with iop.Writer(enabled=iop.io_threads() > 0) as writer:
+        while True:
+            chunk = [held] if held is not None else []
+            held = None
+            for item in decoded:
+                if chunk and (item[1].shape != chunk[0][1].shape or len(chunk) == batch):
+                    held = item
+                    break
+                chunk.append(item)
+            if not chunk:
                 break
-            chunk.append((todo[i][1], np.ascontiguousarray(img)))
-            i += 1
-        orig = chunk[0][1].shape[:2]
-        if isinstance(pred_func, OfflinePredictor) and len(chunk) > 1:
-            stage = _stage_for(pred_func.net, len(chunk))
-            stage.run(torch.from_numpy(np.stack([c[1][:, :, :3] for c in chunk])).to(stage.device))
-            results = [stage.detections(k, orig) for k in range(len(chunk))]
-        else:
-            results = [detect_one_image(c[1], pred_func) for c in chunk]
-        for (out_fn, _), res in zip(chunk, results):
-            with open(out_fn, "w") as f:
-                json.dump(convert_results_to_json(res), f)
-            n += 1
+            orig = chunk[0][1].shape[:2]
+            if isinstance(pred_func, OfflinePredictor) and len(chunk) > 1:
+                stage = _stage_for(pred_func.net, len(chunk))
+                stage.run(torch.from_numpy(np.stack([c[1][:, :, :3] for c in chunk])).to(stage.device))
+                results = [stage.detections(k, orig) for k in range(len(chunk))]
+            else:
+                results = [detect_one_image(c[1], pred_func) for c in chunk]
+            for (out_fn, _), res in zip(chunk, results):
+                writer.submit(dump, out_fn, res)
+                n += 1
     return n
 
 

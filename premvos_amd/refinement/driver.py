@@ -188,14 +188,16 @@ class RefinementEngine:
         self.valid_data = _FeedData()
         self.trainer = _FeedTrainer(self)
 
-    def refine_frames(self, images, proposal_lists):
-        """Several frames of equal size at once: the crops of all of them form one batch (``RefinementNet.refine_group``)."""
+    def refine_frames(self, images, proposal_lists, lane: int = 0):
+        """Several frames of equal size at once: the crops of all of them form one batch (``RefinementNet.refine_group``).
+        ``lane`` selects an independent workspace of the net, so calls on different lanes may run concurrently (each on the
+        calling thread's current stream)."""
         live = [(im, pr) for im, pr in zip(images, proposal_lists) if pr]
         if not live:
             return proposal_lists
         if len(live) == 1 or max(len(pr) for _, pr in live) > self.max_boxes:
             for im, pr in live:
-                self.refine_frame(im, pr)
+                self.refine_frame(im, pr, lane=lane)
             return proposal_lists
         P = _bucket(max(len(pr) for _, pr in live))
         boxes = np.zeros((len(live), P, 4), np.float32)
@@ -203,13 +205,18 @@ class RefinementEngine:
             boxes[g, :len(pr)] = _boxes_from_proposals(pr)
         frames = torch.from_numpy(np.stack([np.array(im[:, :, :3], dtype=np.uint8, order="C") for im, _ in live])).to(self.net.device)
         counts = torch.tensor([len(pr) for _, pr in live], dtype=torch.int32, device=self.net.device)
-        p = self.net.refine_group(frames, torch.from_numpy(boxes).to(self.net.device), counts)
+        p = self.net.refine_group(frames, torch.from_numpy(boxes).to(self.net.device), counts, lane=lane)
+        # only the valid slots of every frame are encoded (padded slots of short frames hold empty masks)
+        valid = torch.tensor([g * P + i for g, (_, pr) in enumerate(live) for i in range(len(pr))], dtype=torch.int64,
+                             device=self.net.device)
+        segs = _encode_on_gpu(p.mask_g.view(-1, *p.mask_g.shape[2:]).index_select(0, valid))   # run boundaries on the GPU
         conf = p.conf_g.cpu().numpy()
-        segs = _encode_on_gpu(p.mask_g.view(-1, *p.mask_g.shape[2:]))        # run boundaries on the GPU, no mask D2H
+        k = 0
         for g, (_, pr) in enumerate(live):
             for i in range(len(pr)):
-                pr[i]["segmentation"] = segs[g * P + i]
+                pr[i]["segmentation"] = segs[k]
                 pr[i]["conf_score"] = str(conf[g, i])
+                k += 1
         return proposal_lists
 
     def refine_boxes(self, frame_u8: np.ndarray, boxes_y0x0y1x1: np.ndarray):
@@ -229,7 +236,7 @@ class RefinementEngine:
             conf[s:s + len(chunk)] = p.conf[:len(chunk)].cpu().numpy()
         return masks, post, conf
 
-    def refine_frame(self, image_rgb: np.ndarray, proposals: List[dict]) -> List[dict]:
+    def refine_frame(self, image_rgb: np.ndarray, proposals: List[dict], lane: int = 0) -> List[dict]:
         if not proposals:
             return proposals
         boxes = _boxes_from_proposals(proposals)
@@ -237,7 +244,7 @@ class RefinementEngine:
         for s in range(0, len(proposals), self.max_boxes):
             chunk = boxes[s:s + self.max_boxes]
             P = self.max_boxes if len(proposals) > self.max_boxes else _bucket(len(chunk))
-            p = self.net.refine(frame, torch.from_numpy(chunk).to(self.net.device), max_boxes=P)
+            p = self.net.refine(frame, torch.from_numpy(chunk).to(self.net.device), max_boxes=P, lane=lane)
             conf = p.conf[:len(chunk)].cpu().numpy()
             segs = _encode_on_gpu(p.mask[:len(chunk)])
             for i in range(len(chunk)):
@@ -284,25 +291,48 @@ def refinement_net_init(config_path: str = "refinement_net/configs/live") -> Ref
 
 def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_dir: str, output_dir: str) -> int:
     """The batch stage: every <seq>/<frame>.json of bb_input_dir -> output_dir (same relative name).  Consecutive frames of
-    equal size are refined as one batch of crops (every box is an independent example, FewShotSegmentationForwarder.py:104-110)."""
+    equal size are refined as one batch of crops (every box is an independent example, FewShotSegmentationForwarder.py:104-110).
+    Host work overlaps the GPU (premvos_amd.io_pipeline): JPEG decode + JSON parsing run ahead on a thread pool, groups
+    alternate over two workspace lanes of the net so one group's RLE packing overlaps the next group's kernels, and the JSON
+    files are written by a background thread -- same bytes as the serial driver (PREMVOS_IO_THREADS=0 PREMVOS_IO_LANES=1)."""
     from PIL import Image
+    from .. import io_pipeline as iop
     group = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
-    jobs = []
-    for jf in sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json"))):
+    files = sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json")))
+
+    def load(jf):
         rel = os.path.relpath(jf, bb_input_dir)
         with open(jf) as f:
             proposals = json.load(f)
         image = np.asarray(Image.open(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")).convert("RGB"))
-        jobs.append((os.path.join(output_dir, rel), image, proposals))
-        if len(jobs) == group or jobs[0][1].shape != image.shape:
-            last = jobs.pop() if jobs[0][1].shape != image.shape else None
+        return os.path.join(output_dir, rel), image, proposals
+
+    def groups():
+        jobs = []
+        for job in iop.prefetch(files, load):
+            if jobs and (len(jobs) == group or jobs[0][1].shape != job[1].shape):
+                yield jobs
+                jobs = []
+            jobs.append(job)
+        if jobs:
+            yield jobs
+
+    n_lanes = iop.io_lanes()
+    streams = [torch.cuda.Stream(device=engine.net.device) for _ in range(n_lanes)] if n_lanes > 1 else [None]
+
+    def work(lane, jobs):
+        if streams[lane] is None:
             engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs])
-            _write_jobs(jobs)
-            jobs = [last] if last is not None else []
-    if jobs:
-        engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs])
-        _write_jobs(jobs)
-    return len(glob.glob(os.path.join(bb_input_dir, "*", "*.json")))
+        else:
+            with torch.cuda.stream(streams[lane]):
+                engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], lane=lane)
+                streams[lane].synchronize()
+        return jobs
+
+    with iop.Writer(enabled=iop.io_threads() > 0) as writer:
+        for jobs in iop.lanes(groups(), work, n_lanes):
+            writer.submit(_write_jobs, jobs)
+    return len(files)
 
 
 def _write_jobs(jobs) -> None:

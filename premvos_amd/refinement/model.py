@@ -13,6 +13,7 @@ decoder inputs are written straight into their concat buffers.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -246,7 +247,7 @@ class _Plan:
             self.run(steps)
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads (IO lanes) keep using the GPU
             self.run(steps)
         if steps is None:
             self.graph = g
@@ -266,6 +267,7 @@ class RefinementNet:
         self.packed: Dict[str, ops.PackedConv] = {}
         self.packed_dw: Dict[str, PackedDW] = {}
         self._plans: Dict[tuple, _Plan] = {}
+        self.max_plans = int(os.environ.get("PREMVOS_REFINE_MAX_PLANS", "12"))
         head = ("image_pooling", "aspp", "concat_projection", "decoder/")
         for k, v in weights.items():
             scope = k.rsplit("/", 1)[0]
@@ -283,12 +285,19 @@ class RefinementNet:
         """``lane`` selects an independent workspace (same weights) so several calls can be in flight; ``frames`` > 1
         builds a plan that refines that many frames (P boxes each) as one batch."""
         key = (P, H, W, with_posterior, lane, frames)
-        if key not in self._plans:
-            p = _Plan(self, P, H, W, with_posterior, frames)
-            if self.use_graph:
-                p.capture()
-            self._plans[key] = p
-        return self._plans[key]
+        p = self._plans.get(key)
+        if p is None:
+            with ops.BUILD_LOCK:                  # lanes of the file drivers run on several threads; building + tuning +
+                p = self._plans.get(key)          # graph capture of a plan is done by one of them at a time
+                if p is None:
+                    p = _Plan(self, P, H, W, with_posterior, frames)
+                    if self.use_graph:
+                        torch.cuda.synchronize()  # capture must not race kernels of another lane's stream
+                        p.capture()
+                    self._plans[key] = p
+                    while len(self._plans) > self.max_plans:          # every plan holds a full Xception activation set
+                        self._plans.pop(next(iter(self._plans)))      # drop the oldest (dicts keep insertion order)
+        return p
 
     def refine(self, frame_rgb: torch.Tensor, boxes_y0x0y1x1: torch.Tensor, max_boxes: Optional[int] = None,
                with_posterior: bool = False, lane: int = 0) -> _Plan:

@@ -111,9 +111,14 @@ def add_ReID(proposals: List[dict], image_fn: str, ReID_net: ReIDEngine) -> List
 
 
 def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: str, output_dir: str) -> int:
+    """Forwarding/ReIDForwarding.py:33-92: every refined proposal with a non-empty mask gains its 128-d embedding.  JSON
+    parsing, RLE -> bbox and JPEG decode run ahead on a thread pool, JSON writing on a background thread
+    (premvos_amd.io_pipeline); the file contents equal the serial loop's."""
     from PIL import Image
-    n = 0
-    for jf in sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json"))):
+    from .. import io_pipeline as iop
+    files = sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json")))
+
+    def load(jf):
         rel = os.path.relpath(jf, bb_input_dir)
         with open(jf) as f:
             proposals = json.load(f)
@@ -124,16 +129,25 @@ def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: st
                 continue
             boxes.append(bb)
             idx.append(i)
+        image = None
         if boxes:
             image = np.asarray(Image.open(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")).convert("RGB"))
-            emb = engine.embed(image, boxes, feed=False)
-            for i, e in zip(idx, emb):
-                proposals[i]["ReID"] = np.array(e).tolist()
-        out_fn = os.path.join(output_dir, rel)
+        return rel, proposals, boxes, idx, image
+
+    def dump(out_fn, proposals):
         os.makedirs(os.path.dirname(out_fn), exist_ok=True)
         with open(out_fn, "w") as f:
             json.dump(proposals, f)
-        n += 1
+
+    n = 0
+    with iop.Writer(enabled=iop.io_threads() > 0) as writer:
+        for rel, proposals, boxes, idx, image in iop.prefetch(files, load):
+            if boxes:
+                emb = engine.embed(image, boxes, feed=False)
+                for i, e in zip(idx, emb):
+                    proposals[i]["ReID"] = np.array(e).tolist()
+            writer.submit(dump, os.path.join(output_dir, rel), proposals)
+            n += 1
     return n
 
 

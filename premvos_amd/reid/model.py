@@ -150,7 +150,7 @@ class _Plan:
             self.run()
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # other host threads (IO lanes) keep using the GPU
             self.run()
         self.graph = g
         return g

@@ -38,4 +38,29 @@ def test_bench_line_through_the_distributed_path():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 20 < r["achieved"] < r["mfma_ceiling_measured"] <= 160
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert "ONE" in d["config"]["parallelism"] and "gather" in d["config"]["parallelism"]
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]
 
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed spawns the ranks itself; with the gloo backend two ranks may share
+    the one GPU of the test box (RCCL, the product backend, needs a device per rank)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"PREMVOS_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PREMVOS_AUTOTUNE": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch",
+                        "2", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step_per_gpu"] == 2
+    assert abs(d["value"] - 2 * 2 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]      # whole-job frames / max-over-ranks time
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PREMVOS_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)

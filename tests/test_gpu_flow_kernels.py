@@ -132,6 +132,20 @@ def test_corr_tiled_multi_tile_shapes(c, h, w):
     assert torch.all(out.buf[..., 81:] == 7.0)          # nothing written beyond the 81 channels
 
 
+def test_corr_unaligned_destination_window():
+    """A channel window that does not start on a 16-byte boundary takes the 4-byte store path."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    f1 = torch.randn((2, 32, 17, 40), generator=g)
+    f2 = torch.randn((2, 32, 17, 40), generator=g)
+    ref = F.leaky_relu(O.correlation_torch(f1, f2), 0.1)
+    out = ops.NHWC.alloc(2, 17, 40, 3 + 81 + 32)
+    ops.corr(_to_nhwc(f1, ops), _to_nhwc(f2, ops), out.slice(3, 81 + 32), 4, 0.1, True)
+    torch.cuda.synchronize()
+    assert (out.slice(3, 81).torch().cpu() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out.slice(3 + 81, 32).torch().cpu(), f1) and out.buf[..., :3].abs().max().item() == 0
+
+
 def test_corr_general_md_falls_back():
     ops = _ops()
     g = torch.Generator().manual_seed(5)

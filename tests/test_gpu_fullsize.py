@@ -44,19 +44,62 @@ def test_proposal_net_full_depth_davis_shape():
     assert n == len(inter["proposal_idx"]) == 100
     fm = p.featuremap.torch().cpu()
     assert (fm - inter["featuremap"]).abs().max().item() < 1e-3 * max(1.0, inter["featuremap"].abs().max().item())
-    # ~57k candidate logits agree to ~1e-4; the selected index sets must be identical unless two logits tie within that
-    same = np.array_equal(p.roi_idx[0, :n].cpu().numpy(), inter["proposal_idx"].astype(np.int32))
-    if not same:
-        a, b = set(p.roi_idx[0, :n].cpu().tolist()), set(inter["proposal_idx"].tolist())
-        assert len(a ^ b) <= 2, (len(a ^ b))
-    else:
-        assert np.array_equal(net.outputs(p, 0)[6], fi)
-        js = convert_results_to_json(res)
-        scale = (nh / 480 + nw / 854) / 2
-        ref = PO.results_to_json(np.minimum(np.maximum(fb / scale, 0), [854, 480, 854, 480]), fp)
-        assert len(js) == len(ref)
-        for x, y in zip(js, ref):
-            assert abs(x["score"] - y["score"]) <= 0.011 and np.abs(np.array(x["bbox"]) - np.array(y["bbox"])).max() <= 0.21
+    rpn = p.rpn_out.buf[0].cpu().numpy()
+    fh, fw = rpn.shape[:2]
+    lab, box = rpn[:, :, :15], rpn[:, :, 15:75].reshape(fh, fw, 15, 4)
+    assert np.abs(lab - inter["rpn_logits"].numpy()).max() < 2e-3 * max(1.0, float(inter["rpn_logits"].abs().max()))
+    # The index logic is checked STRICTLY on the GPU's own fp32 logits / deltas (57 270 candidates agree with the CPU net
+    # only to ~1e-4, so feeding the CPU net's logits could legitimately reorder near-ties): the fused kernel must return
+    # exactly the anchors, in exactly the order, that model.py:169-217 selects from these numbers.
+    dec = PO.decode_bbox_target(box, PO.all_anchors(fh, fw)).reshape(-1, 4)
+    pb, ps, pidx = PO.generate_rpn_proposals(dec, lab.reshape(-1), nh, nw)
+    assert np.array_equal(p.roi_idx[0, :n].cpu().numpy(), pidx.astype(np.int32))
+    assert np.array_equal(p.roi_scores[0, :n].cpu().numpy(), ps)
+    assert np.abs(p.rois[0, :n].cpu().numpy() - pb).max() < 1e-2
+    # same for the inference tail (train.py:275-295, model.py:438-491) on the GPU's own head outputs and RoIs
+    head = p.head.buf.view(p.b, 100, -1)[0].cpu().numpy()
+    rois = p.rois[0, :n].cpu().numpy()
+    tb, tp, tl, ti = PO.fastrcnn_tail(head[:n, :2], head[:n, 2:6].reshape(n, 1, 4), rois, nh, nw)
+    assert np.array_equal(net.outputs(p, 0)[6], ti)
+    js = convert_results_to_json(res)
+    scale = (nh / 480 + nw / 854) / 2
+    ref = PO.results_to_json(np.minimum(np.maximum(tb / scale, 0), [854, 480, 854, 480]).astype(np.float32), tp)
+    assert len(js) == len(ref) > 0
+    for x, y in zip(js, ref):
+        assert abs(x["score"] - y["score"]) <= 0.011 and np.abs(np.array(x["bbox"]) - np.array(y["bbox"])).max() <= 0.11
+    # and the whole CPU net agrees with the GPU net where floats are compared with a tolerance
+    common = np.intersect1d(p.roi_idx[0, :n].cpu().numpy(), inter["proposal_idx"])
+    assert len(common) >= 95, len(common)                  # near-ties may swap a few of the 100 between the two nets
+
+
+def test_proposal_net_full_depth_configs4_shape():
+    """configs[4]: a 1080x1920 frame resizes to 750x1333 (the other aspect-ratio rounding of CustomResize); same strict checks of
+    the index logic on the GPU's own numbers, floats against the CPU net."""
+    from oracle import cv_resize_oracle as CR
+    from premvos_amd.proposal import OfflinePredictor, ProposalNet, detect_one_image
+    w = PO.synth_weights(5)
+    rng = np.random.default_rng(5)
+    img = (rng.integers(0, 8, (1080, 1920, 3)) * 32 + np.linspace(0, 31, 1920, dtype=np.uint8)[None, :, None]).astype(np.uint8)
+    nh, nw = PO.custom_resize_shape(1080, 1920)
+    assert (nh, nw) == (750, 1333)
+    (fb, fp, fl, fi), inter = PO.model_forward(w, CR.resize_linear_u8(img, nw, nh), intermediates=True)
+    net = ProposalNet(w)
+    res = detect_one_image(img, OfflinePredictor(net))
+    p = net.plan(1, nh, nw)
+    n = int(p.roi_count.item())
+    fm = p.featuremap.torch().cpu()
+    assert (fm - inter["featuremap"]).abs().max().item() < 1e-3 * max(1.0, inter["featuremap"].abs().max().item())
+    rpn = p.rpn_out.buf[0].cpu().numpy()
+    fh, fw = rpn.shape[:2]
+    assert (fh, fw) == (46, 83)
+    dec = PO.decode_bbox_target(rpn[:, :, 15:75].reshape(fh, fw, 15, 4), PO.all_anchors(fh, fw)).reshape(-1, 4)
+    pb, ps, pidx = PO.generate_rpn_proposals(dec, rpn[:, :, :15].reshape(-1), nh, nw)
+    assert n == len(pidx) and np.array_equal(p.roi_idx[0, :n].cpu().numpy(), pidx.astype(np.int32))
+    head = p.head.buf.view(p.b, 100, -1)[0].cpu().numpy()
+    tb, tp, tl, ti = PO.fastrcnn_tail(head[:n, :2], head[:n, 2:6].reshape(n, 1, 4), p.rois[0, :n].cpu().numpy(), nh, nw)
+    assert np.array_equal(net.outputs(p, 0)[6], ti) and len(res) == len(ti)
+    for r in res:
+        assert 0 <= r.box[0] <= r.box[2] <= 1920 and 0 <= r.box[1] <= r.box[3] <= 1080
 
 
 def test_refinement_full_depth_480p_and_1080p():

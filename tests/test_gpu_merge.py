@@ -127,3 +127,17 @@ def test_full_size_frame_properties():
     for i in range(20):
         assert np.array_equal(rle.decode(segs[i]), wn[i])
     assert segs[5] == rle.encode(wn[5])
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 210, 4097, 20 * 480 * 854])
+def test_mask_bit_pack_round_trip(n):
+    """premvos_mask_pack_bits_u8 / unpack: np.packbits(bitorder='little') semantics, any length, any non-zero = 1."""
+    from premvos_amd.parallel import _hip_pack_bits, _hip_unpack_bits
+    g = torch.Generator().manual_seed(n)
+    m = (torch.rand(n, generator=g) > 0.5).to(torch.uint8) * torch.randint(1, 255, (n,), generator=g, dtype=torch.uint8)
+    bits = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    _hip_pack_bits(m.cuda(), bits)
+    assert np.array_equal(bits.cpu().numpy(), np.packbits(m.numpy() != 0, bitorder="little"))
+    back = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+    _hip_unpack_bits(bits, back)
+    assert torch.equal(back.cpu(), (m != 0).to(torch.uint8))

@@ -178,3 +178,60 @@ def test_batched_drivers_equal_frame_by_frame_drivers(tmp_path, monkeypatch):
             if x["bbox"] == y["bbox"]:
                 assert abs(float(x["conf_score"]) - float(y["conf_score"])) < 1e-4
                 assert (rle.decode(x["segmentation"]) != rle.decode(y["segmentation"])).mean() < 1e-3
+
+
+def test_overlapped_drivers_write_the_same_bytes_as_serial_drivers(tmp_path, monkeypatch):
+    """premvos_amd.io_pipeline (decode-ahead thread pool, two GPU lanes, background writer) only reorders host work: every
+    .flo / proposal JSON / refined JSON / ReID JSON is byte-identical to the serial drivers' (PREMVOS_IO_THREADS=0, LANES=1)."""
+    run_stages = _harness()
+    roots = []
+    cwd = os.getcwd()
+    try:
+        for tag, threads, nl in (("serial", "0", "1"), ("overlap", "3", "2")):
+            root = tmp_path / tag
+            root.mkdir()
+            _make_tree(root, t=5)
+            monkeypatch.setenv("PREMVOS_IO_THREADS", threads)
+            monkeypatch.setenv("PREMVOS_IO_LANES", nl)
+            monkeypatch.setenv("PREMVOS_DRIVER_BATCH", "2")
+            assert run_stages.main(["--root", str(root), "--flow_weights", "weights/pwc.pth.tar", "--general_weights",
+                                    "weights/proposal_general_weights", "--specific_weights", "weights/specific.pt",
+                                    "--refinement_weights", "weights/refinement_specific_weights"]) == 0
+            os.chdir(cwd)
+            roots.append(root / "output" / "intermediate")
+    finally:
+        os.chdir(cwd)
+    a, b = roots
+    files = sorted(str(p.relative_to(a)) for p in a.rglob("*") if p.is_file())
+    assert files == sorted(str(p.relative_to(b)) for p in b.rglob("*") if p.is_file())
+    assert any(f.endswith(".flo") for f in files) and sum(f.startswith("refined_proposals") for f in files) == 5
+    for f in files:
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+
+
+def test_streaming_driver_writes_the_stage_drivers_tree(tmp_path, monkeypatch):
+    """premvos_amd.stream (one decode per frame, flow / proposals x2 / combine / refinement on three host threads) against the
+    four stage drivers run one after the other like simple_run.sh: same files, same bytes (at matched launch batch sizes)."""
+    from premvos_amd import stream
+    run_stages = _harness()
+    cwd = os.getcwd()
+    monkeypatch.setenv("PREMVOS_DRIVER_BATCH", "2")
+    a_root, b_root = tmp_path / "stages", tmp_path / "stream"
+    args = ["--flow_weights", "weights/pwc.pth.tar", "--general_weights", "weights/proposal_general_weights",
+            "--specific_weights", "weights/specific.pt", "--refinement_weights", "weights/refinement_specific_weights"]
+    try:
+        for root in (a_root, b_root):
+            root.mkdir()
+            _make_tree(root, t=5)
+        assert run_stages.main(["--root", str(a_root)] + args) == 0
+        os.chdir(cwd)
+        assert stream.main(["--root", str(b_root), "--batch", "2"] + args) == 0
+    finally:
+        os.chdir(cwd)
+    a, b = a_root / "output" / "intermediate", b_root / "output" / "intermediate"
+    stages = ("flow", "general_proposals", "specific_proposals", "combined_proposals", "refined_proposals")
+    fa = sorted(str(p.relative_to(a)) for p in a.rglob("*") if p.is_file() and str(p.relative_to(a)).split("/")[0] in stages)
+    fb = sorted(str(p.relative_to(b)) for p in b.rglob("*") if p.is_file())
+    assert fa == fb and len(fa) == 4 + 4 * 5
+    for f in fa:
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f

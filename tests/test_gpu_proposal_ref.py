@@ -82,20 +82,20 @@ def test_roi_align_kernel_on_reference_roi_align():
     from premvos_amd import _lib, ops
     fm, rois, ref = BOX["roi_fm"], BOX["roi_boxes"], BOX["roi_out"]
     _, c, H, W = fm.shape
-    cp = (c + 3) // 4 * 4
-    f = ops.NHWC.alloc(1, H, W, c)
+    cp = (c + 3) // 4 * 4                     # the kernel moves 4 channels per lane: pad the 6-channel fixture with zeros
+    f = ops.NHWC.alloc(1, H, W, cp)
     f.buf[0, :, :, :c] = torch.from_numpy(fm[0]).permute(1, 2, 0).cuda()
     n = len(rois)
     r = torch.zeros((1, 8, 4), device="cuda")
     r[0, :n] = torch.from_numpy(rois).cuda()
     cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
-    out = ops.NHWC.alloc(8, 7, 7, c)
+    out = ops.NHWC.alloc(8, 7, 7, cp)
     # model.py's roi_align takes boxes already in feature-map coordinates: spatial_scale 1
-    _lib.check(_lib.load().premvos_roi_align_f32(f.ptr, f.ps, 1, H, W, c, r.data_ptr(), cnt.data_ptr(), 8, 1.0, 7, out.ptr,
+    _lib.check(_lib.load().premvos_roi_align_f32(f.ptr, f.ps, 1, H, W, cp, r.data_ptr(), cnt.data_ptr(), 8, 1.0, 7, out.ptr,
                                                  out.ps, _lib.current_stream()))
-    assert cp >= c
-    got = out.torch().cpu().numpy()[:n]
+    got = out.torch().cpu().numpy()[:n, :c]
     assert np.abs(got - ref).max() < 1e-5
+    assert np.abs(out.torch().cpu().numpy()[:n, c:]).max() == 0
 
 
 def test_frcnn_tail_kernel_on_reference_fastrcnn_predictions():

@@ -44,7 +44,20 @@ for rep in ("cold", "warm"):            # cold = plan building + autotuning incl
         q_eng = qd.engine_from_config(qd.Config("code/ReID_net/configs/run"))
     stage_time(f"refinement/{rep}", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_proposals/"))
     stage_time(f"reid/{rep}", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_proposals/", f"{inter}/ReID_proposals/"))
-nprops = sum(len(json.load(open(f"{inter}/combined_proposals/seq/{i:05d}.json"))) for i in range(T)) / T
+# the four hot-path stages as ONE streaming process (one decode per frame, stages overlapped on three host threads)
+from premvos_amd import stream
+for rep in ("cold", "warm"):
+    os.system(f"rm -rf {root}/output")
+    stage_time(f"stream A+B+B+C+D/{rep}", lambda: stream.run(root, "seq_to_run.txt", "weights/pwc.pth.tar", "weights/general.pt", "weights/specific.pt",
+                                                            "weights/refine.pt", batch=int(os.environ.get("PREMVOS_STREAM_BATCH", "8"))))
+nprops = sum(len(json.load(open(f"{root}/{inter}/combined_proposals/seq/{i:05d}.json"))) for i in range(T)) / T
 print(f"{T} frames 480x854, {nprops:.1f} combined proposals per frame; DRIVER_BATCH={os.environ.get('PREMVOS_DRIVER_BATCH', 'default')}")
 for k, v in stamps.items():
     print(f"  {k:28s} {v:7.2f} s  = {T / v:6.1f} frames/s")
+serial = sum(stamps[f"{k}/warm"] for k in ("flow", "general_proposals", "specific_proposals", "refinement"))
+summary = {"frames": T, "proposals_per_frame": round(nprops, 1),
+           "stage_drivers_one_after_the_other_fps": round(T / serial, 2), "streaming_driver_fps": round(T / stamps["stream A+B+B+C+D/warm"], 2),
+           "per_stage_fps": {k.split("/")[0]: round(T / v, 1) for k, v in stamps.items() if k.endswith("/warm")}}
+print(json.dumps(summary))
+if len(sys.argv) > 2:
+    json.dump(summary, open(sys.argv[2], "w"), indent=1)
