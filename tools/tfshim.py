@@ -142,7 +142,8 @@ def variable_scope(name=None, default_name=None, values=None, reuse=None):
     n = name if isinstance(name, str) else default_name
     _SCOPE.append(n)
     try:
-        yield types.SimpleNamespace(name="/".join(_SCOPE))
+        full = "/".join(x for x in _SCOPE if x)
+        yield types.SimpleNamespace(name=full, original_name_scope=full + "/")
     finally:
         _SCOPE.pop()
 
@@ -153,7 +154,7 @@ def name_scope(name=None, *a, **k):
 
 
 def get_variable(name, shape) -> T:
-    full = "/".join(_SCOPE + [name])
+    full = "/".join([x for x in _SCOPE if x] + [name])
     shape = tuple(int(s) for s in shape)
     REQUESTED.append((full, shape))
     if full not in VARIABLES:
