@@ -14,6 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
+ABI_VERSION = 5          # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NHWC, OUT_PIXSHUF2 = 0, 1
@@ -93,18 +94,32 @@ def load():
     if _LIB is not None:
         return _LIB
     path = _build.LIB
+    stale = None
     try:
         if _build.needs_build():
-            _build.build_lib()
+            # one builder at a time (every rank of a torchrun job lands here): an exclusive file lock around the check + build
+            import fcntl
+            with open(os.path.join(os.path.dirname(path), ".build.lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if _build.needs_build():
+                    _build.build_lib()
     except Exception as e:  # no hipcc on this box: a prebuilt .so must have travelled
         if not os.path.exists(path):
             raise PremvosError(
                 f"libpremvos_hip.so is missing and could not be built ({e}); the HIP path has no fallback") from e
+        stale = e
     lib = C.CDLL(path)
     lib.premvos_last_error.restype = C.c_char_p
     lib.premvos_last_error.argtypes = []
     lib.premvos_abi_version.restype = C.c_int
     lib.premvos_abi_version.argtypes = []
+    if lib.premvos_abi_version() != ABI_VERSION:
+        # a stale binary with another struct layout / argument list would corrupt arguments silently
+        raise PremvosError(f"{path} has ABI version {lib.premvos_abi_version()}, this package binds version {ABI_VERSION}"
+                           + (f" (rebuilding failed: {stale})" if stale else "") + "; rebuild with python -m premvos_amd.build")
+    if stale is not None:
+        import warnings
+        warnings.warn(f"libpremvos_hip.so is older than its sources and could not be rebuilt ({stale}); using it as is")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -560,4 +560,4 @@ extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* 
   return premvos::check_launch("mfma_f32_calibrate");
 }
 
-extern "C" int premvos_abi_version(void) { return 4; }
+extern "C" int premvos_abi_version(void) { return 5; }   // bump with every change of include/premvos_hip.h

@@ -111,12 +111,15 @@ class _Plan:
             copy_f1 = lvl != 6
             dst = X.slice(GROW_SUM, ND + (fc if copy_f1 else 0))
             if lvl == 6:
-                steps.append((f"corr{lvl}", lambda a=c1, bq=c2, o=dst: ops.corr(a, bq, o, MD, 0.1, False)))
+                f2 = c2
             else:
-                # warp (PWCNet.py:207,220,233,246) fused into the cost volume's f2 staging: the warped map never exists
+                # warp (PWCNet.py:207,220,233,246) then cost volume: the fused premvos_warp_corr_fwd_f32 is bit-identical but
+                # measured slower (the 8x32 tile's halo repeats the bilinear gathers 2.5x), so the warped map is materialised
                 up_flow = X.slice(GROW_SUM + ND + fc, 2)       # written by the level above
-                steps.append((f"warp_corr{lvl}", lambda a=c1, x=c2, f=up_flow, s=FLOW_SCALE[lvl], o=dst:
-                              ops.warp_corr(a, x, f, s, o, MD, 0.1, True)))
+                wbuf = alloc(b, lh, lw, fc, dev)
+                steps.append((f"warp{lvl}", lambda x=c2, f=up_flow, s=FLOW_SCALE[lvl], o=wbuf: ops.warp(x, f, s, o)))
+                f2 = wbuf
+            steps.append((f"corr{lvl}", lambda a=c1, bq=f2, o=dst, cp=copy_f1: ops.corr(a, bq, o, MD, 0.1, cp)))
             off = GROW_SUM
             for i, g in enumerate(GROWTH):
                 xin = X.slice(off, GROW_SUM + od - off)

@@ -233,15 +233,18 @@ def _candidates(d: ConvDesc):
         for st in stages:
             for sk in splits:
                 out.append(((bm << 16) | bn, st, sk, 0, 0))
-            # tail split (fp32 kernel): keep whole multiples of 256 tiles in the main launch and cut the leftover rows
-            # of tiles along K so they too occupy all CUs
+            # tail split (fp32 kernel): the main launch keeps whole rounds of workgroups (a round = 256 CUs x the 1..3
+            # workgroups of this tile that fit a CU) and the leftover rows of tiles are cut along K so that they, too, occupy
+            # the whole chip instead of costing one more, mostly empty round
             mt, ntc = -(-m // bm), -(-d.cout // bn)
-            if d.precision == _lib.PREC_F32 and 256 < nt < 6 * 256 and d.k_pad >= 256:
-                main_rows = (nt // 256) * 256 // ntc
-                tail_rows = mt - main_rows
-                tail_tiles = tail_rows * ntc
-                if main_rows > 0 and 0 < tail_tiles <= 200:
-                    for target in (256, 512):
+            if d.precision == _lib.PREC_F32 and nt > 256 and d.k_pad >= 256:
+                for round_tiles in (256, 512, 768):
+                    main_rows = (nt // round_tiles) * round_tiles // ntc
+                    tail_rows = mt - main_rows
+                    tail_tiles = tail_rows * ntc
+                    if main_rows <= 0 or not (0 < tail_tiles <= 0.6 * round_tiles):
+                        continue
+                    for target in (round_tiles, 2 * round_tiles):
                         ts = min(max(2, round(target / tail_tiles)), 16, d.k_pad // 64)
                         cand = ((bm << 16) | bn, st, -1, tail_rows, ts)
                         if ts > 1 and cand not in out:

@@ -104,6 +104,23 @@ class ProposalStage:
             self.plan.run(self.steps)
         return self.plan
 
+    def json_results(self, orig_hw) -> List[List[dict]]:
+        """What ``forward`` writes for every image of the last batch: convert_results_to_json(detect_one_image(...)) with
+        ONE device-to-host copy per output tensor for the whole batch (the per-image ``detections`` fetches the posteriors and
+        second-head outputs too, seven small synchronous copies per image)."""
+        assert not self.net.mode_mask
+        p = self.plan
+        counts = p.final_count.cpu().numpy()
+        boxes, probs = p.final_boxes.cpu().numpy(), p.final_probs.cpu().numpy()
+        out = []
+        for i in range(self.batch):
+            n = int(counts[i])
+            none = [None] * n
+            res = _to_results(boxes[i, :n].copy(), probs[i, :n].copy(), np.ones((n,), np.int64), none, none, none, self.scale,
+                              orig_hw)
+            out.append(convert_results_to_json(res))
+        return out
+
     def detections(self, i: int, orig_hw) -> List[SecondDetectionResult]:
         boxes, probs, labels, post, sl, sp, _ = self.net.outputs(self.plan, i)
         masks = self.net.masks(self.plan, i) if self.net.mode_mask else None
@@ -226,9 +243,9 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
         img = np.asarray(Image.open(job[0]).convert("RGB"))[:, :, ::-1]             # cv2.imread gives BGR (train.py:500)
         return job[1], np.ascontiguousarray(img)
 
-    def dump(out_fn, res):
+    def dump(out_fn, js):
         with open(out_fn, "w") as f:
-            json.dump(convert_results_to_json(res), f)
+            json.dump(js, f)
 
     decoded = iop.prefetch(todo, load)            # JPEG decode runs ahead on a thread pool, JSON is written in the background
     n, held = 0, None
@@ -244,12 +261,12 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
             if not chunk:
                 break
             orig = chunk[0][1].shape[:2]
-            if isinstance(pred_func, OfflinePredictor) and len(chunk) > 1:
+            if isinstance(pred_func, OfflinePredictor) and not pred_func.net.mode_mask:
                 stage = _stage_for(pred_func.net, len(chunk))
                 stage.run(torch.from_numpy(np.stack([c[1][:, :, :3] for c in chunk])).to(stage.device))
-                results = [stage.detections(k, orig) for k in range(len(chunk))]
+                results = stage.json_results(orig)
             else:
-                results = [detect_one_image(c[1], pred_func) for c in chunk]
+                results = [convert_results_to_json(detect_one_image(c[1], pred_func)) for c in chunk]
             for (out_fn, _), res in zip(chunk, results):
                 writer.submit(dump, out_fn, res)
                 n += 1

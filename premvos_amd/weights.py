@@ -224,7 +224,7 @@ def read_table(path: str, verify: bool = True) -> Dict[bytes, bytes]:
     return out
 
 
-def load_tf_checkpoint(prefix: str, verify: bool = False) -> Dict[str, np.ndarray]:
+def load_tf_checkpoint(prefix: str, verify: bool = True) -> Dict[str, np.ndarray]:
     """Every variable of a TF tensor-bundle checkpoint as numpy arrays (TF layouts, TF names)."""
     table = read_table(prefix + ".index")
     num_shards = 1
@@ -431,11 +431,64 @@ def reid_weights_to_tf(w: Dict[str, object]) -> Dict[str, np.ndarray]:
     return v
 
 
+def expected_keys(kind: str, weights: Dict[str, object]) -> List[str]:
+    """The names the net of ``kind`` packs, for the depth read off ``weights`` (product tables: RESNET layout of
+    proposal/model.py, module_plan of refinement/model.py); the names themselves are pinned by the reference's graph code
+    (tests/golden/{proposal,deeplab}_host_refs.json: every variable the graph requests)."""
+    keys: List[str] = []
+    if kind == "proposal":
+        blocks = tuple(len({k.split("/")[1] for k in weights if k.startswith(f"group{g}/block")}) for g in range(4))
+        keys += ["conv0/W", "conv0/bn"]
+        cin = 64
+        for g, (feat, cnt) in enumerate(zip((64, 128, 256, 512), blocks)):
+            for i in range(cnt):
+                p = f"group{g}/block{i}"
+                for c in ("conv1", "conv2", "conv3"):
+                    keys += [f"{p}/{c}/W", f"{p}/{c}/bn"]
+                if cin != 4 * feat:
+                    keys += [f"{p}/convshortcut/W", f"{p}/convshortcut/bn"]
+                cin = 4 * feat
+        for h in ("rpn/conv0", "rpn/class", "rpn/box", "fastrcnn/class", "fastrcnn/box", "secondclassification/class"):
+            keys += [h + "/W", h + "/b"]
+    elif kind == "refinement":
+        from .refinement.model import module_plan
+        nm = len({k.split("/")[2] for k in weights if k.startswith("middle_flow/block1/unit_")})
+        def conv(scope):
+            return [scope + "/weights", scope + "/BatchNorm"]
+        def dw(scope):
+            return [scope + "/depthwise_weights", scope + "/BatchNorm"]
+        keys += conv("entry_flow/conv1_1") + conv("entry_flow/conv1_2")
+        for prefix, _, _, skip, _, _, _ in module_plan(nm):
+            for i in (1, 2, 3):
+                keys += dw(f"{prefix}/separable_conv{i}_depthwise") + conv(f"{prefix}/separable_conv{i}_pointwise")
+            if skip == "conv":
+                keys += conv(prefix + "/shortcut")
+        keys += conv("image_pooling") + conv("aspp0") + conv("concat_projection") + conv("decoder/feature_projection0")
+        for i in (1, 2, 3):
+            keys += dw(f"aspp{i}_depthwise") + conv(f"aspp{i}_pointwise")
+        for j in (0, 1):
+            keys += dw(f"decoder/decoder_conv{j}_depthwise") + conv(f"decoder/decoder_conv{j}_pointwise")
+        keys += ["logits/features/weights", "logits/features/biases"]
+    return keys
+
+
 def load_any(path: str, kind: str) -> Dict[str, object]:
-    """``path`` = a torch pickle of the name->tensor dict, or a TF checkpoint prefix (what simple_run.sh passes)."""
+    """``path`` = a TF checkpoint prefix (what simple_run.sh passes: ``<path>.index`` + ``<path>.data-*``, checksums verified)
+    or a torch pickle of the name->tensor dict.  Optimizer slots / global_step in a TF checkpoint are ignored by the name
+    maps; a weight the net needs that the file does not hold is an error that lists the missing names."""
     if os.path.exists(path + ".index"):
         v = load_tf_checkpoint(path)
-        return {"proposal": proposal_weights_from_tf, "refinement": refinement_weights_from_tf,
-                "reid": reid_weights_from_tf}[kind](v)
-    import torch
-    return torch.load(path, map_location="cpu")
+        w = {"proposal": proposal_weights_from_tf, "refinement": refinement_weights_from_tf,
+             "reid": reid_weights_from_tf}[kind](v)
+    elif os.path.exists(path):
+        import torch
+        w = torch.load(path, map_location="cpu")
+        if not isinstance(w, dict):
+            raise ValueError(f"{path}: expected a pickled dict of name -> tensor, got {type(w).__name__}")
+    else:
+        raise FileNotFoundError(f"no checkpoint at {path!r}: neither the TF bundle {path}.index / {path}.data-* nor a torch "
+                                f"pickle of that name exists")
+    missing = [k for k in expected_keys(kind, w) if k not in w]
+    if missing:
+        raise KeyError(f"{path}: {len(missing)} weight(s) the {kind} net needs are missing, e.g. {missing[:8]}")
+    return w

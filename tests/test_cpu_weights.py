@@ -1,4 +1,6 @@
 """TF tensor-bundle reader/writer + variable-name maps (no TensorFlow, no GPU)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -83,3 +85,35 @@ def test_refinement_name_and_layout_map(tmp_path):
     _same(W.load_any(prefix, "refinement"), w)
     torch.save(w, str(tmp_path / "w.pt"))
     _same(W.load_any(str(tmp_path / "w.pt"), "refinement"), w)
+
+
+def test_load_any_errors_are_explicit(tmp_path):
+    """a missing file, a checkpoint with missing variables and a corrupted tensor are reported as such."""
+    import pytest
+    import torch
+    from premvos_amd import synth
+    from premvos_amd import weights as W
+    with pytest.raises(FileNotFoundError, match="neither the TF bundle"):
+        W.load_any(str(tmp_path / "nope"), "proposal")
+    w = synth.proposal_weights(0, (1, 1, 1, 1))
+    tfv = W.proposal_weights_to_tf(w)
+    # optimizer slots and bookkeeping variables of a training checkpoint are ignored
+    tfv["conv0/W/Momentum"] = np.zeros_like(tfv["conv0/W"])
+    tfv["global_step"] = np.array(7, np.int64)
+    W.save_tf_checkpoint(str(tmp_path / "full"), tfv)
+    back = W.load_any(str(tmp_path / "full"), "proposal")
+    assert sorted(k for k in back if not k.startswith("maskrcnn/")) == sorted(k for k in w if not k.startswith("maskrcnn/"))
+    del tfv["group2/block0/conv2/W"], tfv["rpn/box/b"]
+    W.save_tf_checkpoint(str(tmp_path / "partial"), tfv)
+    with pytest.raises(KeyError, match="group2/block0/conv2/W"):
+        W.load_any(str(tmp_path / "partial"), "proposal")
+    # a flipped byte in the data shard fails the (now default) tensor checksum
+    shard = [p for p in os.listdir(tmp_path) if p.startswith("full.data")][0]
+    raw = bytearray(open(tmp_path / shard, "rb").read())
+    raw[100] ^= 0xFF
+    open(tmp_path / shard, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        W.load_any(str(tmp_path / "full"), "proposal")
+    torch.save([1, 2], tmp_path / "list.pt")
+    with pytest.raises(ValueError, match="pickled dict"):
+        W.load_any(str(tmp_path / "list.pt"), "refinement")

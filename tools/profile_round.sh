@@ -29,6 +29,14 @@ python tools/pmc_traffic.py "$(find $OUT/${TAG}_pmc_FETCH_SIZE -name '*counter_c
   "$(find $OUT/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_conv_hbm_traffic.json" \
   > /dev/null
 cp "$OUT/${TAG}_conv_hbm_traffic.json" profiles/${TAG}_conv_hbm_traffic.json      # bench.py reads the traffic figure from here
+# 4. the cost-volume kernel on its own (rocprofv3 kernel stats of tools/time_corr.py: the 5 pyramid levels of a 16-pair step)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof_corr" -o corr -- \
+   python "$REPO/tools/time_corr.py" 16 > "$OUT/${TAG}_time_corr.log" 2>&1)
+cp "$(find $OUT/${TAG}_prof_corr -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_corr_kernel_stats.csv"; rm -rf "$OUT/${TAG}_prof_corr"
+# 5. two ranks through the self-launching path (gloo: both ranks share this box's one GPU; RCCL needs a device per rank)
+PREMVOS_BENCH_BACKEND=gloo python bench.py --gpus 2 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline \
+   > "$OUT/${TAG}_bench_2ranks_gloo.log" 2>&1
+grep '^{' "$OUT/${TAG}_bench_2ranks_gloo.log" | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
 python bench.py > "$OUT/${TAG}_bench_fp32.log" 2>&1
 grep '^{' "$OUT/${TAG}_bench_fp32.log" | tail -1 > "$OUT/${TAG}_bench_fp32.json"
 # keep only the small summaries (the traces are tens of MB)
