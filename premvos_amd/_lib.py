@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 5          # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
+ABI_VERSION = 6          # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NHWC, OUT_PIXSHUF2 = 0, 1
@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("slope", C.c_float), ("out_mode", C.c_int32), ("cout_ps", C.c_int32),
         ("tile_hint", C.c_int32), ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("precision", C.c_int32), ("stage_k", C.c_int32), ("wgt_lo", C.c_void_p),
-        ("tail_m_tiles", C.c_int32), ("tail_split_k", C.c_int32),
+        ("tail_m_tiles", C.c_int32), ("tail_split_k", C.c_int32), ("wgt_wino", C.c_void_p),
     ]
 
 

@@ -1,0 +1,308 @@
+// 3x3 / stride-1 dense convolution by Winograd F(2x2, 3x3) on the fp32 matrix pipe: 2.25x fewer multiplies than the implicit
+// GEMM of conv_igemm_f32.hip for the layers where that kernel is contraction-bound (ResNet conv2 of every bottleneck, the RPN
+// 3x3, PWC-Net's DenseNet estimators and dc_conv1).  Same data path as the GEMM kernel (NHWC input slice with a pixel stride,
+// LDS-staged operands, v_mfma_f32_32x32x2_f32, XCD-aware tile order), different algebra:
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// * the filter transform U = G g G^T is done once by the host (ops.pack_conv: 16 matrices [cout_pad][k_pad], k = cin);
+// * the INPUT transform is fused into the A-operand staging: every row of B^T has exactly two non-zeros (+-1), so component
+//   (xi, nu) of a patch is +-d[i1][j1] +- d[i1][j2] +- d[i2][j1] +- d[i2][j2] -- four 16-byte loads and three adds per staged
+//   float4 instead of one load; no transformed-input tensor ever exists in HBM;
+// * the 16 components are 16 independent GEMMs M_c[tile][cout] = V_c[tile][cin] * U_c[cout][cin]; a workgroup computes one
+//   128x128 tile of ONE component and writes it raw to the workspace slab of that component (the split-K slab layout);
+//   consecutive workgroups of an XCD walk the 16 components of the same (tile rows, cout columns) block, so the 4x4 patches
+//   they all gather stay in that XCD's L2;
+// * wino_output_kernel applies A^T . A, bias (+ folded BatchNorm), residual, activation and writes the 2x2 pixels.
+//
+// fp32 throughout (exact products on the MFMA pipe); against the direct convolution the result differs by the usual Winograd
+// rounding (~1e-6 relative: sums of up to four inputs / nine weights are formed before the multiply).
+// Reference call sites replaced: the same framework conv calls as premvos_conv2d_f32 (include/premvos_hip.h).
+#include "common.h"
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+namespace {
+
+constexpr int KB = 16, RS = KB + 4, KU = KB / 4;
+
+// row r of B^T = +d[I1[r]] + S2[r] * d[I2[r]]
+__device__ __constant__ int W_I1[4] = {0, 1, 2, 1};
+__device__ __constant__ int W_I2[4] = {2, 2, 1, 3};
+__device__ __constant__ float W_S2[4] = {-1.f, 1.f, -1.f, -1.f};
+
+// per-component select (a float4 ?: compiles to a scratch-memory select on this toolchain)
+__device__ __forceinline__ float4 sel4(bool c, const float4& v) {
+  return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 3) void wino_gemm_kernel(const premvos_conv_desc p, const float* __restrict__ wgt_wino,
+                                                        float* __restrict__ ws, const int tiles_y, const int tiles_x,
+                                                        const int m_tiles, const int n_tiles) {
+  constexpr int NT = 256;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
+  constexpr int A_PER_T = BM * KU / NT, B_PER_T = (BN * KU + NT - 1) / NT;
+  constexpr int BUF = (BM + BN) * RS;
+  static_assert(BM * KU % NT == 0, "staging must divide evenly");
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  float(*lds)[BUF] = reinterpret_cast<float(*)[BUF]>(lds_dyn);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
+  const int Mt = p.n * tiles_y * tiles_x;
+  int tile_m, tile_n, comp;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    comp = v & 15;
+    const int rest = v >> 4;
+    tile_n = rest % n_tiles;
+    tile_m = rest / n_tiles;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int xi = comp >> 2, nu = comp & 3;
+  const int i1 = W_I1[xi], i2 = W_I2[xi], j1 = W_I1[nu], j2 = W_I2[nu];
+  const float si = W_S2[xi], sj = W_S2[nu];
+
+  const int j4 = (tid % KU) * 4;
+  const float* src[A_PER_T][4];
+  bool ok[A_PER_T][4];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int row = (tid / KU) + i * (NT / KU);
+    const int m = m0 + row;
+    const bool rok = m < Mt;
+    const int mm = rok ? m : 0;
+    const int tpi = tiles_y * tiles_x;
+    const int n = mm / tpi, rem = mm - n * tpi;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int y0 = 2 * ty - p.pt, x0 = 2 * tx - p.pl;
+    const float* img = p.in + (long)n * p.h * p.w * p.in_ps;
+    const int ys[2] = {y0 + i1, y0 + i2}, xs[2] = {x0 + j1, x0 + j2};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool in = rok && (unsigned)ys[a] < (unsigned)p.h && (unsigned)xs[b] < (unsigned)p.w;
+        ok[i][a * 2 + b] = in;
+        src[i][a * 2 + b] = img + (in ? ((long)ys[a] * p.w + xs[b]) * p.in_ps : 0);
+      }
+  }
+  const float* wrow[B_PER_T];
+  bool wok[B_PER_T];
+#pragma unroll
+  for (int i = 0; i < B_PER_T; ++i) {
+    const int row = (tid / KU) + i * (NT / KU);
+    wok[i] = row < BN && n0 + row < p.cout_pad;
+    wrow[i] = wgt_wino + ((long)comp * p.cout_pad + (wok[i] ? n0 + row : 0)) * p.k_pad + j4;
+  }
+
+  float4 ra[A_PER_T][4], rb[B_PER_T];
+  auto gload = [&](int kt) {
+    const int c = kt * KB + j4;
+    const bool kok = c < p.cin_pad;
+    const int cc = kok ? c : 0;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ra[i][t] = *reinterpret_cast<const float4*>(src[i][t] + cc);
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + kt * KB);
+  };
+  auto lstore = [&](int buf, int kt) {
+    const bool kok = kt * KB + j4 < p.cin_pad;
+    float* a = &lds[buf][0];
+    float* b = &lds[buf][BM * RS];
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int row = (tid / KU) + i * (NT / KU);
+      const float4 d11 = sel4(kok && ok[i][0], ra[i][0]), d12 = sel4(kok && ok[i][1], ra[i][1]);
+      const float4 d21 = sel4(kok && ok[i][2], ra[i][2]), d22 = sel4(kok && ok[i][3], ra[i][3]);
+      float4 v;      // (d[i1][j1] + sj d[i1][j2]) + si (d[i2][j1] + sj d[i2][j2])
+      v.x = (d11.x + sj * d12.x) + si * (d21.x + sj * d22.x);
+      v.y = (d11.y + sj * d12.y) + si * (d21.y + sj * d22.y);
+      v.z = (d11.z + sj * d12.z) + si * (d21.z + sj * d22.z);
+      v.w = (d11.w + sj * d12.w) + si * (d21.w + sj * d22.w);
+      *reinterpret_cast<float4*>(a + row * RS + j4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int row = (tid / KU) + i * (NT / KU);
+      if (BN * KU % NT == 0 || row < BN) *reinterpret_cast<float4*>(b + row * RS + j4) = sel4(wok[i] && kt * KB + j4 < p.k_pad, rb[i]);
+    }
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int KT = (p.k_pad + KB - 1) / KB;
+  gload(0);
+  lstore(0, 0);
+  __syncthreads();
+  const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+    const float* a = &lds[buf][wm0 * RS + frag_off];
+    const float* b = &lds[buf][(BM + wn0) * RS + frag_off];
+#pragma unroll
+    for (int h = 0; h < KB / 8; ++h) {
+      float4 af[MT], bf[NTL];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1, kt + 1);
+    __syncthreads();
+  }
+
+  // raw component tile -> ws[comp][tile][ncols]
+  const int ncols = n_tiles * BN;
+  float* dst = ws + (long)comp * Mt * ncols;
+#pragma unroll
+  for (int ni = 0; ni < NTL; ++ni) {
+    const int col = n0 + wn0 + ni * 32 + (lane & 31);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < Mt) dst[(long)m * ncols + col] = acc[mi][ni][r];
+      }
+  }
+}
+
+// Y = A^T M A per (tile, 4 couts), A^T = [[1,1,1,0],[0,1,-1,-1]], + bias + residual + activation -> the tile's 2x2 pixels.
+__global__ __launch_bounds__(256) void wino_output_kernel(const premvos_conv_desc p, const float* __restrict__ ws,
+                                                          const int tiles_y, const int tiles_x, const int ncols) {
+  const int Mt = p.n * tiles_y * tiles_x, c4 = p.cout / 4;
+  const long total = (long)Mt * c4;
+  const long cstride = (long)Mt * ncols;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int m = idx / c4, col = (idx - (long)m * c4) * 4;
+    const float* q = ws + (long)m * ncols + col;
+    float4 s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(q + (0 * 4 + j) * cstride), b = *reinterpret_cast<const float4*>(q + (1 * 4 + j) * cstride);
+      const float4 c = *reinterpret_cast<const float4*>(q + (2 * 4 + j) * cstride), d = *reinterpret_cast<const float4*>(q + (3 * 4 + j) * cstride);
+      s0[j] = make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
+      s1[j] = make_float4(b.x - c.x - d.x, b.y - c.y - d.y, b.z - c.z - d.z, b.w - c.w - d.w);
+    }
+    float4 y[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float4* s = a ? s1 : s0;
+      y[a][0] = make_float4(s[0].x + s[1].x + s[2].x, s[0].y + s[1].y + s[2].y, s[0].z + s[1].z + s[2].z, s[0].w + s[1].w + s[2].w);
+      y[a][1] = make_float4(s[1].x - s[2].x - s[3].x, s[1].y - s[2].y - s[3].y, s[1].z - s[2].z - s[3].z, s[1].w - s[2].w - s[3].w);
+    }
+    const int tpi = tiles_y * tiles_x;
+    const int n = m / tpi, rem = m - n * tpi;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const float4 bv = p.bias != nullptr ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = 2 * ty + a, ox = 2 * tx + b;
+        if (oy >= p.ho || ox >= p.wo) continue;
+        const long pix = ((long)n * p.ho + oy) * p.wo + ox;
+        float v[4] = {y[a][b].x + bv.x, y[a][b].y + bv.y, y[a][b].z + bv.z, y[a][b].w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (p.res != nullptr) v[e] += p.res[pix * p.res_ps + col + e];
+          if (p.act == PREMVOS_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          else if (p.act == PREMVOS_ACT_LEAKY) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+          else if (p.act == PREMVOS_ACT_SIGMOID) v[e] = 1.f / (1.f + expf(-v[e]));
+          p.out[pix * p.out_ps + col + e] = v[e];
+        }
+      }
+  }
+}
+
+}  // namespace
+
+namespace premvos {
+
+bool conv_wino_applicable(const premvos_conv_desc& d) {
+  return d.wgt_wino != nullptr && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == 1 && d.dw == 1 &&
+         d.out_mode == PREMVOS_OUT_NHWC && d.precision == PREMVOS_PREC_F32 && d.cout % 4 == 0 && d.k_pad >= d.cin_pad &&
+         d.ho == d.h + 2 * d.pt - 2 && d.wo == d.w + 2 * d.pl - 2 && d.pt >= 0 && d.pl >= 0;
+}
+
+static inline void wino_geometry(const premvos_conv_desc& d, int bn, int* ty, int* tx, long* mt, int* n_tiles) {
+  *ty = (d.ho + 1) / 2;
+  *tx = (d.wo + 1) / 2;
+  *mt = (long)d.n * *ty * *tx;
+  *n_tiles = cdiv(d.cout, bn);
+}
+
+static inline int wino_bn(const premvos_conv_desc& d) { return d.cout <= 32 ? 32 : d.cout <= 64 ? 64 : 128; }
+
+long conv_wino_workspace_bytes(const premvos_conv_desc& d) {
+  int ty, tx, nt;
+  long mt;
+  const int bn = wino_bn(d);
+  wino_geometry(d, bn, &ty, &tx, &mt, &nt);
+  return 16L * mt * nt * bn * (long)sizeof(float);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wino(const premvos_conv_desc& d, hipStream_t s) {
+  int ty, tx, n_tiles;
+  long mt;
+  wino_geometry(d, BN, &ty, &tx, &mt, &n_tiles);
+  premvos_conv_desc w = d;
+  w.k_pad = cdiv((int)d.cin_pad, 16) * 16;              // the transformed filters are packed with k = cin only
+  const int m_tiles = cdiv((int)mt, BM);
+  constexpr int LDS_BYTES = 2 * (BM + BN) * RS * (int)sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles * 16), dim3(256), LDS_BYTES, s, w, d.wgt_wino,
+                     d.workspace, ty, tx, m_tiles, n_tiles);
+  int rc = check_launch("wino_gemm");
+  if (rc) return rc;
+  const long total = mt * (d.cout / 4);
+  int g = (int)((total + 255) / 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(g), dim3(256), 0, s, d, d.workspace, ty, tx, n_tiles * BN);
+  return check_launch("wino_output");
+}
+
+int conv_wino(const premvos_conv_desc& d, hipStream_t s) {
+  if (d.workspace == nullptr || d.workspace_bytes < conv_wino_workspace_bytes(d))
+    return fail(PREMVOS_EINVAL, "conv2d(winograd): needs %ld workspace bytes", conv_wino_workspace_bytes(d));
+  if ((long)d.n * ((d.ho + 1) / 2) * ((d.wo + 1) / 2) >= (1L << 27)) return fail(PREMVOS_EINVAL, "conv2d(winograd): too many tiles");
+  // stage_k == 64 (set by the plan-time autotuner) selects 64-tile-row workgroups: twice as many, half as long -- the better
+  // choice when the 128-row grid ends in a mostly empty last round of workgroups
+  const bool bm64 = d.stage_k == 64;
+  switch (wino_bn(d)) {
+    case 32: return launch_wino<128, 32, 4, 1>(d, s);
+    case 64: return bm64 ? launch_wino<64, 64, 2, 2>(d, s) : launch_wino<128, 64, 2, 2>(d, s);
+    default: return bm64 ? launch_wino<64, 128, 2, 2>(d, s) : launch_wino<128, 128, 2, 2>(d, s);
+  }
+}
+
+}  // namespace premvos

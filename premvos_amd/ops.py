@@ -67,6 +67,7 @@ class PackedConv:
     cout_ps: int = 0          # >0: transposed-conv phases (PIXSHUF2)
     precision: int = 0        # _lib.PREC_*; bf16 modes: wgt / wgt_lo are bfloat16 [cout_pad][k_pad], k_pad % 32 == 0
     wgt_lo: Optional[torch.Tensor] = None
+    wgt_wino: Optional[torch.Tensor] = None      # fp32 3x3 layers: the 16 Winograd F(2x2,3x3) filter transforms [16][cout_pad][r16(cin_pad)]
 
 
 def default_precision() -> str:
@@ -97,11 +98,33 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
         b[:cout] = bias.detach().to(torch.float32).cpu()
         b = b.to(device)
     if prec == _lib.PREC_F32:
-        return PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
+        pk = PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
+        if (kh, kw) == (3, 3) and cout % 4 == 0 and cin >= WINO_MIN_CIN and wino_enabled():
+            pk.wgt_wino = pack_winograd(w, cin_pad, cout_pad).to(device)
+        return pk
     hi = full.to(torch.bfloat16)
     lo = (full - hi.float()).to(torch.bfloat16) if prec == _lib.PREC_BF16X3 else None
     return PackedConv(hi.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec,
                       lo.to(device).contiguous() if lo is not None else None)
+
+
+WINO_MIN_CIN = 16
+
+
+def wino_enabled() -> bool:
+    import os
+    return os.environ.get("PREMVOS_WINOGRAD", "1") != "0"
+
+
+def pack_winograd(w_oihw: torch.Tensor, cin_pad: int, cout_pad: int) -> torch.Tensor:
+    """U[4*xi+nu] = (G g G^T)[xi][nu] of every (cout, cin) filter g (BatchNorm scale already folded into ``w_oihw``), computed in
+    float64 and rounded once; each packed like a 1x1 conv: [cout_pad][roundup(cin_pad, 16)], zero padded."""
+    cout, cin = w_oihw.shape[:2]
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    U = torch.einsum("xi,ocij,nj->xnoc", G, w_oihw.double(), G).reshape(16, cout, cin)
+    out = torch.zeros((16, cout_pad, _r(cin_pad, 16)), dtype=torch.float32)
+    out[:, :cout, :cin] = U.float()
+    return out.contiguous()
 
 
 def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
@@ -175,6 +198,7 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     d.workspace, d.workspace_bytes = None, 0
     d.precision = pk.precision
     d.wgt_lo = pk.wgt_lo.data_ptr() if pk.wgt_lo is not None else None
+    d.wgt_wino = pk.wgt_wino.data_ptr() if pk.wgt_wino is not None else None
     return d
 
 
@@ -209,7 +233,12 @@ BUILD_LOCK = __import__("threading").RLock()
 
 def _sig(d: ConvDesc):
     return (d.n, d.h, d.w, d.cin, d.ho, d.wo, d.cout, d.kh, d.kw, d.sh, d.sw, d.dh, d.dw, bool(d.res), d.out_mode,
-            d.precision, d.in_ps, d.out_ps)
+            d.precision, d.in_ps, d.out_ps, bool(d.wgt_wino))
+
+
+def wino_applicable(d: ConvDesc) -> bool:
+    return bool(d.wgt_wino) and d.precision == _lib.PREC_F32 and (d.kh, d.kw, d.sh, d.sw, d.dh, d.dw) == (3, 3, 1, 1, 1, 1) \
+        and d.out_mode == OUT_NHWC and d.cout % 4 == 0 and d.ho == d.h + 2 * d.pt - 2 and d.wo == d.w + 2 * d.pl - 2
 
 
 def _candidates(d: ConvDesc):
@@ -226,6 +255,10 @@ def _candidates(d: ConvDesc):
     if d.precision == _lib.PREC_F32 and d.cout <= 2 and d.out_mode == OUT_NHWC and d.kh * d.kw * d.cin_pad >= 32 \
             and d.cout * d.k_pad * 4 <= 150 * 1024:
         out.append((1, 0, -1, 0, 0))               # tile_hint 1 = the direct (non-MFMA) kernel for 1-2 output channels
+    if wino_applicable(d):
+        out.append((2, 0, -1, 0, 0))               # tile_hint 2 = Winograd F(2x2,3x3) (csrc/conv_wino_f32.hip), 128 tile rows
+        if d.cout > 32:
+            out.append((2, 64, -1, 0, 0))          # ... with 64-tile-row workgroups
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((128, 128), (128, 64), (64, 128))) else [16]

@@ -1,0 +1,66 @@
+"""Winograd F(2x2,3x3) conv kernel (csrc/conv_wino_f32.hip) against torch's fp64 convolution and against the implicit-GEMM
+kernel on the same descriptor: 3x3 / stride 1, odd map sizes, channel counts that are not multiples of the tiles, fused bias /
+residual / activation, output into a channel window."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from premvos_amd import ops
+    return ops
+
+
+def _nhwc(t, ops, ps=None, coff=0):
+    n, c, h, w = t.shape
+    x = ops.NHWC.alloc(n, h, w, (ps or (coff + c)))
+    x.buf[..., coff:coff + c] = t.permute(0, 2, 3, 1).cuda()
+    return x.slice(coff, c)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,act,res", [(1, 64, 64, 17, 23, "relu", True), (2, 117, 128, 32, 40, "leaky", False),
+                                                    (1, 256, 256, 46, 83, "relu", False), (3, 20, 36, 9, 5, "none", True),
+                                                    (2, 565, 32, 16, 28, "leaky", False), (1, 1024, 1024, 12, 21, "relu", False)])
+def test_winograd_matches_torch_and_the_gemm_kernel(n, cin, cout, h, w, act, res):
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    r = torch.randn((n, cout, h, w), generator=g) if res else None
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    ref = {"relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t}[act](ref)
+    a = {"relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY, "none": ops.ACT_NONE}[act]
+    pk = ops.pack_conv(wt, b)
+    assert pk.wgt_wino is not None and tuple(pk.wgt_wino.shape) == (16, pk.cout_pad, (pk.cin_pad + 15) // 16 * 16)
+    xin = _nhwc(x, ops, ps=(cin + 3) // 4 * 4 + 8, coff=4)
+    rin = _nhwc(r, ops) if res else None
+    outs = {}
+    for tag, hint in (("wino", 2), ("gemm", (128 << 16) | (128 if cout > 64 else 64 if cout > 32 else 32))):
+        out = ops.NHWC.alloc(n, h, w, cout + 8)
+        out.buf.fill_(3.0)
+        ops.conv2d(xin, pk, out.slice(4, cout), pad=(1, 1), act=a, res=rin, tile_hint=hint)
+        torch.cuda.synchronize()
+        assert torch.all(out.buf[..., :4] == 3.0) and torch.all(out.buf[..., 4 + cout:] == 3.0)      # window respected
+        outs[tag] = out.slice(4, cout).torch().cpu().double()
+    scale = max(1.0, ref.abs().max().item())
+    assert (outs["gemm"] - ref).abs().max().item() < 2e-5 * scale
+    assert (outs["wino"] - ref).abs().max().item() < 5e-5 * scale            # Winograd rounding: sums before the products
+    assert (outs["wino"] - outs["gemm"]).abs().max().item() < 5e-5 * scale
+
+
+def test_winograd_is_refused_where_it_does_not_apply():
+    from premvos_amd import _lib
+    ops = _ops()
+    x = ops.NHWC.alloc(1, 8, 8, 16)
+    pk = ops.pack_conv(torch.randn((16, 16, 3, 3)), None)
+    out = ops.NHWC.alloc(1, 4, 4, 16)
+    with pytest.raises(_lib.PremvosError, match="Winograd"):
+        ops.conv2d(x, pk, out, stride=(2, 2), pad=(1, 1), tile_hint=2)          # stride 2
+    pk1 = ops.pack_conv(torch.randn((16, 16, 1, 1)), None)
+    assert pk1.wgt_wino is None
