@@ -126,7 +126,7 @@ def roofline(pipe, batch):
     samples = [[] for _ in items]
     for _ in range(reps):
         evs = []
-        for _, _, fn, _, _ in items:
+        for _, _, fn, _, _, _ in items:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); fn(); b.record()
             evs.append((a, b))
@@ -135,13 +135,13 @@ def roofline(pipe, batch):
             samples[i].append(a.elapsed_time(b))
     tot = [sorted(x)[len(x) // 2] for x in samples]          # median per launch: robust to a throttling transient
     # refinement launches run once per group of frames: weight their time by the calls per step
-    mult = [pipe.refine_calls_per_step if st == "refine" else 1 for st, _, _, _, _ in items]
+    mult = [pipe.refine_calls_per_step if st == "refine" else 1 for st, _, _, _, _, _ in items]
     ms = sum(t * m for t, m in zip(tot, mult))
     flops = sum(it[3] for it in items)
     nl = sum(mult)
     ach = flops / (ms * 1e-3) / 1e12
     per_stage = {}
-    for (st, _, _, f, _), t, m in zip(items, tot, mult):
+    for (st, _, _, f, _, _), t, m in zip(items, tot, mult):
         a = per_stage.setdefault(st, [0.0, 0.0])
         a[0] += f
         a[1] += t * m
@@ -169,8 +169,16 @@ def roofline(pipe, batch):
     cb.record()
     cb.synchronize()
     ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel (every dense conv of the three nets; the seven 1-2 channel heads run "
-                                       "on conv_smalln_kernel and are counted with their algorithmic FLOPs)", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+    return {"bound": "mfma", "kernel": "the dense-conv step of the three nets on the fp32 MFMA pipe: conv_igemm_f32_kernel (implicit GEMM; "
+                                       "incl. its k-slab / tail-split launches + reduce) or, where the plan-time autotuner measured it faster, "
+                                       "wino_gemm_kernel + wino_output_kernel (Winograd F(2x2,3x3) for 3x3 stride-1 layers: 2.25x fewer "
+                                       "multiplies, so `achieved` -- ALGORITHMIC 2*M*K*N FLOPs / time -- can exceed what the pipe issues); the "
+                                       "seven 1-2 channel heads run on conv_smalln_kernel and are counted with their algorithmic FLOPs",
+            "winograd_layers": sum(1 for it in items if it[5].tile_hint == 2),
+            # FLOPs the matrix pipe actually issues (a Winograd layer issues 16/36 of its algorithmic 3x3 FLOPs) / time / peak
+            "mfma_issue_frac": round(sum(it[3] * (16.0 / 36.0 if it[5].tile_hint == 2 else 1.0) for it in items) / (ms * 1e-3) / 1e12
+                                     / PEAK_F32_TFLOPS, 4),
+            "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": round(alg_bytes / nl), "mfma_ceiling_measured": round(ceiling, 1),
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),

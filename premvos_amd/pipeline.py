@@ -91,8 +91,8 @@ class FramePipeline:
                 "specific_boxes": ps.final_boxes, "specific_probs": ps.final_probs, "specific_count": ps.final_count}
 
     def conv_steps(self):
-        """(stage, name, launch fn, algorithmic FLOPs per step, algorithmic HBM bytes per step) of every conv_igemm launch
-        of one step (bench roofline)."""
+        """(stage, name, launch fn, algorithmic FLOPs per step, algorithmic HBM bytes per step, descriptor) of every dense-conv
+        step of one pipeline step (bench roofline)."""
         from . import ops
         out = []
         G = self.refine_group
@@ -102,5 +102,5 @@ class FramePipeline:
                                        ("refine", rp.steps, rp, self.refine_calls_per_step)):
             conv = [(n, f) for n, f in steps if n.startswith("conv:")]
             assert len(conv) == len(plan.descs)
-            out += [(tag, n, f, plan.flops[n] * mult, ops.algorithmic_bytes(d) * mult) for (n, f), d in zip(conv, plan.descs)]
+            out += [(tag, n, f, plan.flops[n] * mult, ops.algorithmic_bytes(d) * mult, d) for (n, f), d in zip(conv, plan.descs)]
         return out

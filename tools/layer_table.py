@@ -2,10 +2,10 @@
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from oracle import proposal_oracle as PO, pwc_oracle as O, refinement_oracle as RO
+from premvos_amd import synth
 from premvos_amd.pipeline import FramePipeline
 B = int(os.environ.get('PREMVOS_BENCH_BATCH', '16'))
-pipe = FramePipeline(O.synth_state_dict(0), PO.synth_weights(0), PO.synth_weights(1), RO.synth_weights(0), batch=B, boxes_per_frame=20)
+pipe = FramePipeline(synth.pwc_state_dict(0), synth.proposal_weights(0), synth.proposal_weights(1), synth.refinement_weights(0), batch=B, boxes_per_frame=20)
 fa, fb = bench.synth_frames(B, 0); fa, fb = fa.cuda(), fb.cuda(); boxes = bench.synth_boxes(B, 0).cuda()
 for _ in range(2): pipe.step(fa, fb, boxes)
 torch.cuda.synchronize()
@@ -13,13 +13,14 @@ items = pipe.conv_steps()
 samples = [[] for _ in items]
 for _ in range(5):
     evs = []
-    for _, _, fn, _, _ in items:
+    for _, _, fn, _, _, _ in items:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); evs.append((a, b))
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(evs): samples[i].append(a.elapsed_time(b))
 rows = []
-for (st, name, fn, fl, _), sm in zip(items, samples):
+for (st, name, fn, fl, _, d), sm in zip(items, samples):
+    name = name + (" [winograd]" if d.tile_hint == 2 else "")
     ms = sorted(sm)[2]; mult = pipe.refine_calls_per_step if st == "refine" else 1
     per = fl / mult
     rows.append((ms * mult - fl / 120e9, st, name, ms, per / ms / 1e9, mult))

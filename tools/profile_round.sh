@@ -25,8 +25,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 unset PREMVOS_PIPELINE_SERIAL
 cd "$REPO"
+STEPS=$(python -c "import json;print(json.load(open('$OUT/${TAG}_bench_under_rocprof_serial.json'))['roofline']['launches_per_step'])")
 python tools/pmc_traffic.py "$(find $OUT/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" \
-  "$(find $OUT/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_conv_hbm_traffic.json" \
+  "$(find $OUT/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_conv_hbm_traffic.json" $STEPS \
   > /dev/null
 cp "$OUT/${TAG}_conv_hbm_traffic.json" profiles/${TAG}_conv_hbm_traffic.json      # bench.py reads the traffic figure from here
 # 4. the cost-volume kernel on its own (rocprofv3 kernel stats of tools/time_corr.py: the 5 pyramid levels of a 16-pair step)
@@ -37,6 +38,7 @@ cp "$(find $OUT/${TAG}_prof_corr -name '*kernel_stats.csv' | head -1)" "$OUT/${T
 PREMVOS_BENCH_BACKEND=gloo python bench.py --gpus 2 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline \
    > "$OUT/${TAG}_bench_2ranks_gloo.log" 2>&1
 grep '^{' "$OUT/${TAG}_bench_2ranks_gloo.log" | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
+python tools/layer_table.py > "$OUT/${TAG}_layer_table.txt" 2>&1
 python bench.py > "$OUT/${TAG}_bench_fp32.log" 2>&1
 grep '^{' "$OUT/${TAG}_bench_fp32.log" | tail -1 > "$OUT/${TAG}_bench_fp32.json"
 # keep only the small summaries (the traces are tens of MB)
