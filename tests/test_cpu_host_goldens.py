@@ -77,3 +77,19 @@ def test_config_getters_and_errors_match_reference(tmp_path):
     fn.write_text('# comment\n{"a": 1,\n  # another\n "b": "x"}\n')
     c = Config(str(fn), '{"b": "y"}')
     assert c.int("a") == 1 and c.string("b") == "y"
+
+
+def test_box_iou_against_reference_np_box_ops():
+    """proposal_net/utils/np_box_ops.py (area / intersection / iou on [y0,x0,y1,x1] boxes, float64) run on seeded boxes: the
+    oracle's TF-style NMS IoU (float32, the arithmetic of non_max_suppression_op.cc) must agree with it to float32 round-off on
+    well-formed boxes -- the IoU definition both the RPN and the per-class NMS of the hot path rest on."""
+    from oracle import proposal_oracle as PO
+    b = G["np_box_ops"]
+    b1, b2 = np.array(b["boxes1"]), np.array(b["boxes2"])
+    area = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    assert np.allclose(area, b["area"], rtol=1e-12)
+    iou = np.array([[PO.iou_tf(x.astype(np.float32), y.astype(np.float32)) for y in b2] for x in b1])
+    assert iou.shape == np.array(b["iou"]).shape
+    assert np.abs(iou - np.array(b["iou"])).max() < 1e-6
+    inter = np.array(b["intersection"])
+    assert ((inter > 0) == (iou > 0)).all()

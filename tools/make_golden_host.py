@@ -5,7 +5,7 @@ TensorFlow nor cv2 (run in the build container, where /root/reference exists; th
   * proposal_net/utils/np_box_ops.py         area / intersection / iou / ioa on seeded boxes
   * proposal_net/combine_general_and_specific.py   run as a script on a small seeded tree of proposal JSON files
   * refinement_net/datasets/util/Normalization.py  normalize() on a seeded image
-  * refinement_net/core/Config.py            typed getters + error behaviour on refinement_net/configs/run
+  * refinement_net/core/Config.py            typed getters + error behaviour on a synthetic config with that file's key types
 
 Usage: python tools/make_golden_host.py [/root/reference]"""
 import importlib.util
@@ -96,8 +96,25 @@ def main():
                       "mean": nm.IMAGENET_RGB_MEAN.tolist(), "std": nm.IMAGENET_RGB_STD.tolist()}
 
     cf = _load(os.path.join(CODE, "refinement_net", "core", "Config.py"), "ref_config")
-    cfg_path = os.path.join(CODE, "refinement_net", "configs", "run")
-    c = cf.Config(cfg_path)
+    # a SYNTHETIC config with the key names / value types of refinement_net/configs/run (the fixture must hold data, not a copy
+    # of one of the reference's files): '#' comment lines, strings, ints, floats, bools, lists, a nested dict, an int-key dict
+    cfg_text = "\n".join([
+        "# synthetic config for the Config-getter fixture",
+        "{",
+        '  "model": "synthetic_refiner", "load": "weights/some/prefix", "gpus": "0",',
+        '  "image_input_dir": "data/frames", "model_dir": "models/",',
+        "  # sizes",
+        '  "batch_size": 3, "input_size_train": [385, 385], "bbox_jitter_factor": 0.05,',
+        '  "use_bbox_guidance": true, "need_train": false,',
+        '  "augmentors_train": ["bbox_jitter", "flip"],',
+        '  "learning_rates": "{1: 1e-05, 4: 2.5e-06}",',
+        '  "network": {"deeplab": {"class": "DeepLabV3Plus", "n_features": 2}, "output": {"class": "SegmentationSoftmax", "from": ["deeplab"]}}',
+        "}", ""])
+    with tempfile.TemporaryDirectory() as td:
+        cfg_path = os.path.join(td, "run")
+        with open(cfg_path, "w") as f:
+            f.write(cfg_text)
+        c = cf.Config(cfg_path)
     calls = [("string", "load", None), ("string", "model", None), ("dir", "image_input_dir", None),
              ("dir", "model_dir", None), ("int", "batch_size", None), ("int", "missing_int", 7),
              ("bool", "use_bbox_guidance", None), ("bool", "need_train", None), ("float", "bbox_jitter_factor", None),
@@ -114,8 +131,7 @@ def main():
             res.append({"method": meth, "key": key, "default": default, "value": v})
         except Exception as e:                                   # noqa: BLE001 -- the error type IS the vector
             res.append({"method": meth, "key": key, "default": default, "raises": type(e).__name__})
-    with open(cfg_path) as f:
-        g["config"] = {"text": f.read(), "calls": res, "has": {k: c.has(k) for k in ("load", "nope")}}
+    g["config"] = {"text": cfg_text, "calls": res, "has": {k: c.has(k) for k in ("load", "nope")}}
 
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
