@@ -325,6 +325,19 @@ def main():
                                   f"({xchg.nbytes if xchg else 0} B: flow f32, masks bit-packed, boxes/scores/conf) to rank 0"},
     }
     if rank == 0:
+        # secondary, profile-sourced: the same path measured FILE TO FILE (JPEG decode, .flo / JSON / COCO-RLE writing included) by
+        # tools/time_drivers.py on a GPU box earlier in the round -- `value` above is the HBM-resident metric, never this
+        import glob
+        ftf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_file_to_file.json")))
+        if ftf and a.frame == "480p":
+            try:
+                f2f = json.load(open(ftf[-1]))
+                out["file_to_file"] = {"streaming_driver_fps": f2f["streaming_driver_fps"],
+                                       "stage_drivers_one_after_the_other_fps": f2f["stage_drivers_one_after_the_other_fps"],
+                                       "frames": f2f["frames"], "proposals_per_frame": f2f["proposals_per_frame"], "n_gpus": 1,
+                                       "source": "profiles/" + os.path.basename(ftf[-1]) + " (tools/time_drivers.py; not measured by this run)"}
+            except Exception:
+                pass
         if not a.no_roofline:
             out["roofline"] = roofline(pipe, B)
         if world == 1 and not a.no_cpu_baseline:

@@ -108,15 +108,22 @@ def encode_masks(masks: ArrayLike) -> List[Dict[str, object]]:
     return out
 
 
-def warp_proposals(proposals: Sequence[Dict], optflow: Union[str, ArrayLike]) -> List[Dict]:
+def warp_proposals(proposals: Sequence[Dict], optflow: Union[str, ArrayLike], device_masks: bool = False) -> List[Dict]:
     """merge_functions.py:219-241: every proposal's 'mask' warped to the next frame, with its RLE, bbox and scores.
-    ``optflow`` is a .flo filename (as in the reference) or a flow array / CUDA tensor [h,w,2]."""
+    ``optflow`` is a .flo filename (as in the reference) or a flow array / CUDA tensor [h,w,2].
+    ``device_masks=True`` keeps the masks RESIDENT: the 'mask' entries of the result are uint8 CUDA tensors (views of one
+    [n,h,w] tensor) instead of numpy arrays, and CUDA-tensor 'mask' entries are accepted on input, so a merge loop that feeds
+    the result back into ``warp_proposals`` / ``mask_iou`` / ``encode_masks`` frame after frame never moves a mask over
+    PCIe -- only the few hundred run boundaries of each RLE come to the host."""
     flow = get_flow(optflow) if isinstance(optflow, str) else optflow
     if not proposals:
         return []
-    warped = warp_masks([p["mask"] for p in proposals], flow)
+    masks = [p["mask"] for p in proposals]
+    if all(isinstance(m, torch.Tensor) and m.is_cuda for m in masks):
+        masks = torch.stack([m.to(torch.uint8) for m in masks])
+    warped = warp_masks(masks, flow)
     segs = encode_masks(warped)
-    wm = warped.cpu().numpy()
+    wm = warped if device_masks else warped.cpu().numpy()
     out = []
     for i, p in enumerate(proposals):
         out.append({"segmentation": segs[i], "bbox": rle.to_bbox(segs[i]), "score": 0.5 * (p["final_score"] + 1),

@@ -141,3 +141,20 @@ def test_mask_bit_pack_round_trip(n):
     back = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
     _hip_unpack_bits(bits, back)
     assert torch.equal(back.cpu(), (m != 0).to(torch.uint8))
+
+
+def test_warp_proposals_with_resident_masks():
+    """SURVEY 8(f1) residency: CUDA masks in, CUDA masks out, same RLE / bbox / scores as the host-mask path."""
+    from premvos_amd import mergetrack as MT
+    m = _masks(11, 3, 40, 56)
+    f = _flow(12, 40, 56, 4.0)
+    props = [{"mask": m[i], "id": i + 1, "final_score": 0.2 * i, "object_score": 0.5} for i in range(3)]
+    host = MT.warp_proposals(props, f)
+    dm = torch.from_numpy(m).cuda()
+    dev = MT.warp_proposals([dict(p, mask=dm[i]) for i, p in enumerate(props)], torch.from_numpy(f).cuda(), device_masks=True)
+    for a, b in zip(dev, host):
+        assert isinstance(a["mask"], torch.Tensor) and a["mask"].is_cuda
+        assert np.array_equal(a["mask"].cpu().numpy(), b["mask"])
+        assert a["segmentation"] == b["segmentation"] and a["bbox"] == b["bbox"] and a["score"] == b["score"]
+    again = MT.warp_proposals(dev, torch.from_numpy(f).cuda(), device_masks=True)          # the result feeds the next frame
+    assert len(again) == 3 and again[0]["mask"].is_cuda
