@@ -155,6 +155,23 @@ def test_whole_graph_oracle_vs_reference_build_graph():
     assert np.array_equal(fl, GRAPH["final_labels"])
 
 
+def test_mask_head_oracle_vs_reference_build_graph():
+    """The same pass with config.MODE_MASK on (train.py:297-309, model.py:494-509, tensorpack Deconv2D): final_masks."""
+    ref = np.load(os.path.join(GOLD, "proposal_ref_mask.npz"))
+    assert np.array_equal(ref["final_boxes"], GRAPH["final_boxes"])              # the mask branch changes nothing upstream
+    w, img, blocks = _synth_inputs()
+    (fb, fp, fl, fi), it = PO.model_forward(w, img, blocks, intermediates=True)
+    masks = PO.maskrcnn_masks(w, it["featuremap"], ref["final_boxes"], blocks[3])
+    assert masks.shape == ref["final_masks"].shape == (len(fp), 14, 14)
+    assert np.abs(masks - ref["final_masks"]).max() < 1e-4
+    # ... and the checkpoint names / TF layouts the branch asks for are the importer's (Deconv2D W = [kh, kw, out, in])
+    from premvos_amd import synth
+    from premvos_amd import weights as W
+    tfv = W.proposal_weights_to_tf(synth.proposal_weights(3, blocks))
+    for n, shp in HR["graph"]["mask_variables"]:
+        assert tuple(tfv[n].shape) == tuple(shp), n
+
+
 def test_variable_names_the_graph_requests_are_the_importers():
     """Every variable Model._build_graph asked its checkpoint for (name + TF-layout shape) is what
     premvos_amd.weights.proposal_weights_from_tf consumes, and the mapped dict has every key ProposalNet packs."""

@@ -132,3 +132,21 @@ def test_variable_names_the_graph_requests_are_the_importers():
             assert all(torch.equal(a[j], b[j]) for j in a), k
         else:
             assert torch.equal(a, b), k
+
+
+def test_output_layer_oracle_vs_reference_segmentation_softmax():
+    """SegmentationSoftmax's eval branch (network/SegmentationOutputLayers.py:17-135, built as configs/run:34-36 says) executed on
+    the stand-in: frame-size mask and foreground posterior for five crop boxes (full frame, interior, 2x3 pixels, borders)."""
+    ref = np.load(os.path.join(GOLD, "deeplab_ref_output.npz"))
+    assert HR["output_layer_extractions"] == sorted(["segmentation_posteriors", "segmentation_mask_original_size",
+                                                      "segmentation_posteriors_original_size"])
+    h, w = (int(v) for v in ref["frame_hw"])
+    for i, crop in enumerate(ref["crops"]):
+        lg = torch.from_numpy(ref[f"logits{i}"]).permute(2, 0, 1)[None].contiguous()
+        mask, post = RO.output_layer(lg, tuple(int(v) for v in crop), h, w)
+        want = np.unpackbits(ref[f"mask{i}"])[:h * w].reshape(h, w)
+        assert np.array_equal(mask, want), i
+        assert np.abs(post - ref[f"post{i}"]).max() < 1e-6, i
+        # the 385x385 probability the crop-size one is resized from
+        p385 = torch.softmax(RO.resize_bilinear_tf(lg, RO.INPUT_SIZE, RO.INPUT_SIZE, False), dim=1)[0, 1].numpy()
+        assert np.abs(p385[::4, ::4] - ref[f"post385_{i}"]).max() < 1e-6

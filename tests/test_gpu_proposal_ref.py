@@ -52,6 +52,24 @@ def test_whole_graph_hip_vs_reference_build_graph():
     assert np.abs(sp - GRAPH["second_final_posterior"]).max() < 1e-3
 
 
+def test_mask_head_hip_vs_reference_build_graph():
+    """MODE_MASK branch (train.py:297-309, model.py:494-509) of the reference-executed graph: final_masks [M,14,14]."""
+    from premvos_amd import synth
+    from premvos_amd.proposal import OfflinePredictor, ProposalNet
+    ref = np.load(os.path.join(GOLD, "proposal_ref_mask.npz"))
+    g = HR["graph"]
+    blocks = tuple(g["blocks"])
+    w = synth.proposal_weights(3, blocks)
+    fr, _ = synth.video_frames(1, g["image_hw"][0], g["image_hw"][1], rank=7)
+    img = np.ascontiguousarray(fr[0].numpy()[:, :, ::-1])
+    net = ProposalNet(w, blocks, use_graph=False, mode_mask=True)
+    out = OfflinePredictor(net)(img)
+    assert np.abs(out[0] - ref["final_boxes"]).max() < 0.05 and len(out[1]) == len(ref["final_probs"])
+    masks = net.masks(net.plan(1, *g["image_hw"]))
+    assert masks.shape == ref["final_masks"].shape
+    assert np.abs(masks - ref["final_masks"]).max() < 2e-3
+
+
 def test_rpn_proposals_kernel_on_reference_box_arithmetic():
     """generate_rpn_proposals(decode_bbox_target(...)) of model.py:113-217 on seeded deltas with score ties: the fused kernel
     must return the reference's boxes and scores in the reference's order."""

@@ -39,3 +39,35 @@ def test_whole_graph_hip_vs_reference_multi_scale_logits():
     assert _close(nhwc(p.aspp_out)[:, :, :, ::2], REF["aspp_sub"], 1e-3)
     assert _close(nhwc(p.decoder_out)[:, ::4, ::4, ::8], REF["decoder_sub"], 1e-3)
     assert _close(nhwc(p.logits), REF["logits"], 1e-3)
+
+
+def test_refine_output_kernel_on_reference_segmentation_softmax():
+    """premvos_refine_output_f32 against SegmentationSoftmax's eval branch executed by tools/make_golden_deeplab.py
+    (SegmentationOutputLayers.py:17-135): frame-size masks / posteriors of five crop boxes + the forwarder's conf score."""
+    from premvos_amd import _lib, ops
+    ref = np.load(os.path.join(GOLD, "deeplab_ref_output.npz"))
+    h, w = (int(v) for v in ref["frame_hw"])
+    crops = ref["crops"]
+    P = len(crops)
+    li = ops.NHWC.alloc(P, 97, 97, 2)
+    for i in range(P):
+        li.buf[i, :, :, :2] = torch.from_numpy(ref[f"logits{i}"]).cuda()
+    cr = torch.from_numpy(crops.astype(np.int32)).cuda()
+    cnt = torch.tensor([P], dtype=torch.int32, device="cuda")
+    mask = torch.zeros((P, h, w), dtype=torch.uint8, device="cuda")
+    post = torch.zeros((P, h, w), device="cuda")
+    conf = torch.zeros((P,), device="cuda")
+    lib = _lib.load()
+    ws = torch.zeros((int(lib.premvos_refine_output_workspace_bytes(P, 385, h, w)) + 3) // 4, device="cuda")
+    _lib.check(lib.premvos_refine_output_f32(li.ptr, li.ps, 97, 97, cr.data_ptr(), cnt.data_ptr(), P, 385, h, w, mask.data_ptr(),
+                                             post.data_ptr(), conf.data_ptr(), ws.data_ptr(), _lib.current_stream()))
+    for i in range(P):
+        want_m = np.unpackbits(ref[f"mask{i}"])[:h * w].reshape(h, w)
+        want_p = ref[f"post{i}"]
+        gp, gm = post[i].cpu().numpy(), mask[i].cpu().numpy()
+        assert np.abs(gp - want_p).max() < 1e-5, i
+        diff = gm != want_m
+        assert not diff.any(), (i, int(diff.sum()))
+        c = want_p.copy()                                   # FewShotSegmentationForwarder.py:144-148 on the reference's outputs
+        c[want_m == 0] = 1 - want_p[want_m == 0]
+        assert abs(float(conf[i]) - float((2 * c - 1).mean())) < 1e-5

@@ -8,6 +8,8 @@ script runs the whole flow stage at import) and MergeTrack/merge_functions.py:19
 Fixtures (data only; weights / inputs are regenerated from premvos_amd.synth seeds by the tests):
   deeplab_ref.npz           one pass of model.multi_scale_logits on a [1,385,385,4] input, 2 middle-flow units (sub-sampled): end points
                             (entry_flow/block2 skip), Xception output, ASPP output, decoder features, logits
+  deeplab_ref_output.npz    SegmentationSoftmax's eval branch (SegmentationOutputLayers.py:17-135, configs/run:34-36) on five crop boxes:
+                            logits in, frame-size mask (bit-packed) and foreground posterior out
   deeplab_host_refs.json    the Xception-65 block table xception_65() builds, every conv / depthwise layer the graph code
                             instantiates (scope, kernel, stride, rate, padding, shapes), every variable it requests,
                             scale_dimension values, encode_bbox_as_mask_np cases, .flo bytes
@@ -108,6 +110,38 @@ def run_graph():
     return arrays, list(slimshim.LAYERS), list(tfshim.REQUESTED)
 
 
+def output_layer_cases():
+    """SegmentationSoftmax (network/SegmentationOutputLayers.py:17-135) constructed as configs/run:34-36 asks (resize_logits) in
+    inference mode with batch 1 and a crop box: the eval branch resizes the logits to the label size, soft-maxes, arg-maxes the
+    LOGITS, resizes mask (nearest) / foreground probability (bilinear) to the crop size and zero-pads to the frame.  loss="ce"
+    instead of the config's "bootstrapped_ce": the loss is built but never fetched at inference."""
+    slimshim.install_output_layer_api(tf)
+    from refinement_net.core import Extractions
+    from refinement_net.datasets import DataKeys
+    from refinement_net.network import SegmentationOutputLayers as S
+    rng = np.random.default_rng(29)
+    H, W = 120, 200
+    out = {"frame_hw": np.array([H, W], np.int32)}
+    crops = [(0, 0, 120, 200), (10, 20, 100, 190), (50, 60, 52, 63), (0, 150, 120, 200), (37, 3, 119, 61)]
+    out["crops"] = np.array(crops, np.int32)
+    for i, crop in enumerate(crops):
+        coarse = rng.standard_normal((1, 9, 9, 2)).astype(np.float32) * 3
+        logits = np.kron(coarse, np.ones((1, 11, 11, 1), np.float32))[:, 1:98, 1:98] + rng.standard_normal((1, 97, 97, 2)).astype(np.float32) * 0.25
+        nid = {DataKeys.SEGMENTATION_LABELS: T(np.zeros((1, SIZE, SIZE, 1), np.uint8)),
+               DataKeys.SEGMENTATION_LABELS_ORIGINAL_SIZE: T(np.zeros((1, H, W, 1), np.uint8)),
+               DataKeys.CROP_BOXES_y0x0y1x1: T(np.array([crop], np.int32))}
+        layer = S.SegmentationSoftmax("output", [T(logits)], types.SimpleNamespace(num_classes=lambda: 2), nid,
+                                      types.SimpleNamespace(is_training=False, network_name="net"), resize_logits=True, loss="ce")
+        mask = layer.extractions[Extractions.SEGMENTATION_MASK_ORIGINAL_SIZE].a
+        post = layer.extractions[Extractions.SEGMENTATION_POSTERIORS_ORIGINAL_SIZE].a
+        assert mask.shape == post.shape == (1, H, W) and mask.dtype == np.int64 and post.dtype == np.float32
+        out[f"logits{i}"] = logits[0].astype(np.float32)
+        out[f"mask{i}"] = np.packbits(mask[0].astype(np.uint8))
+        out[f"post{i}"] = post[0]
+        out[f"post385_{i}"] = layer.extractions[Extractions.SEGMENTATION_POSTERIORS].a[0, ::4, ::4]
+    return out, sorted(layer.extractions)
+
+
 def extract_function(path, name):
     src = open(path).read()
     node = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == name][0]
@@ -147,9 +181,11 @@ def main():
         back = ns["get_flow"](fn)
     g["flo"] = {"uv": uv.tolist(), "bytes_b64": base64.b64encode(raw).decode(), "reader_roundtrip_equal": bool(np.array_equal(back, uv))}
     np.savez_compressed(os.path.join(GOLD, "deeplab_ref.npz"), **arrays)
+    ol, g["output_layer_extractions"] = output_layer_cases()
+    np.savez_compressed(os.path.join(GOLD, "deeplab_ref_output.npz"), **ol)
     with open(os.path.join(GOLD, "deeplab_host_refs.json"), "w") as f:
         json.dump(g, f, indent=1)
-    for fn in ("deeplab_ref.npz", "deeplab_host_refs.json"):
+    for fn in ("deeplab_ref.npz", "deeplab_ref_output.npz", "deeplab_host_refs.json"):
         print(fn, os.path.getsize(os.path.join(GOLD, fn)), "bytes")
     print("layers:", len(layers), "variables:", len(requested), "logits", arrays["logits"].shape)
 

@@ -10,6 +10,7 @@ Fixtures are data only (inputs are regenerated from premvos_amd.synth seeds by t
   proposal_ref_anchors.npz   data.get_all_anchors(): the full 83x83x15x4 field
   proposal_ref_graph.npz     one inference pass of Model._build_graph on a 112x160 image, ResNet depth (1,1,2,1):
                              featuremap, RPN logits / deltas, proposals, RoIAlign output / conv5 feature (sub-sampled), head logits, final detections
+  proposal_ref_mask.npz      the same pass with config.MODE_MASK = True: final_masks [M,14,14] (+ the boxes / labels they belong to)
   proposal_ref_boxops.npz    decode_bbox_target / clip_boxes / generate_rpn_proposals / roi_align / fastrcnn_predictions on
                              seeded tensors incl. score ties
 
@@ -121,6 +122,8 @@ def run_graph():
     fh, fw = IMG_H // config.ANCHOR_STRIDE, IMG_W // config.ANCHOR_STRIDE
     inputs = [T(img), T(np.zeros((fh, fw, config.NUM_ANCHOR), np.int32)), T(np.ones((fh, fw, config.NUM_ANCHOR, 4), np.float32)),
               T(np.zeros((0, 4), np.float32)), T(np.zeros((0,), np.int64)), T(np.zeros((0,), np.int64))]
+    if config.MODE_MASK:                                   # train.py:111: one more (unused at inference) input, gt_masks
+        inputs.append(T(np.zeros((0, IMG_H, IMG_W), np.uint8)))
     train.Model()._build_graph(inputs)
     a = lambda t: np.asarray(t.a)                                                     # noqa: E731
     out = {"image_bgr_f32": img, "featuremap": a(cap["pretrained_resnet_conv4"]),
@@ -135,6 +138,19 @@ def run_graph():
         out[k] = a(tfshim.NAMED[k])
     out["fastrcnn_all_boxes"] = a(tfshim.NAMED["fastrcnn_all_boxes"])
     return out, list(tfshim.REQUESTED)
+
+
+def run_mask_graph():
+    """The same pass with MODE_MASK on (train.py:297-309, model.py:494-509): RoIAlign on the final boxes -> conv5 (the shared
+    weights) -> Deconv2D 2x2 s2 + ReLU -> 1x1 -> per-label gather -> sigmoid.  Off in --forward (train.py:636-637)."""
+    config.MODE_MASK = True
+    try:
+        out, requested = run_graph()
+    finally:
+        config.MODE_MASK = False
+    return {"final_masks": np.asarray(tfshim.NAMED["final_masks"].a), "final_boxes": out["final_boxes"],
+            "final_labels": out["final_labels"], "final_probs": out["final_probs"]}, \
+        [r for r in requested if r[0].startswith("maskrcnn/")]
 
 
 def box_ops():
@@ -179,9 +195,13 @@ def main():
                    "variables": [[n, list(s)] for n, s in requested]}
     np.savez_compressed(os.path.join(GOLD, "proposal_ref_graph.npz"), **graph)
     np.savez_compressed(os.path.join(GOLD, "proposal_ref_boxops.npz"), **box_ops())
+    mask, mask_vars = run_mask_graph()
+    hr["graph"]["mask_variables"] = [[n, list(s)] for n, s in mask_vars]
+    np.savez_compressed(os.path.join(GOLD, "proposal_ref_mask.npz"), **mask)
     with open(os.path.join(GOLD, "proposal_host_refs.json"), "w") as f:
         json.dump(hr, f, indent=1)
-    for fn in ("proposal_ref_anchors.npz", "proposal_ref_graph.npz", "proposal_ref_boxops.npz", "proposal_host_refs.json"):
+    for fn in ("proposal_ref_anchors.npz", "proposal_ref_graph.npz", "proposal_ref_boxops.npz", "proposal_ref_mask.npz",
+               "proposal_host_refs.json"):
         print(fn, os.path.getsize(os.path.join(GOLD, fn)), "bytes")
     print("final detections:", len(graph["final_probs"]), "proposals:", len(graph["proposal_scores"]))
 

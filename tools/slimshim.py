@@ -203,4 +203,50 @@ def install():
     return tf
 
 
+def install_output_layer_api(tf):
+    """The extra TF names refinement_net/network/{Layer, Util, SegmentationOutputLayers}.py and core/Measures.py touch at import
+    or in SegmentationSoftmax's eval branch (SegmentationOutputLayers.py:17-135): legacy resize_images / nearest-neighbour
+    resize, 3-argument where, sparse softmax cross entropy (the loss is built even at inference), py_func, unstack."""
+    import sys
+    tf.__path__ = []
+    for n in ("tensorflow.python", "tensorflow.python.training", "tensorflow.python.training.moving_averages",
+              "tensorflow.python.layers", "tensorflow.python.layers.utils"):
+        sys.modules[n] = tfshim._Anything(n)
+        sys.modules[n].__path__ = []
+    tf.image.resize_images = lambda images, size, method=0, align_corners=False: resize_bilinear(images, size, align_corners)
+
+    def resize_nearest_neighbor(images, size, align_corners=False, name=None):
+        """TF1 legacy: src = min(floor(dst * in / out), in - 1), the scale and the product in float32."""
+        a = _np(images)
+        oh, ow = (int(v) for v in (size.a if isinstance(size, T) else [int(_np(s)) for s in size]))
+        h, w = a.shape[1:3]
+        yi = np.minimum(np.floor(np.arange(oh, dtype=np.float32) * (np.float32(h) / np.float32(oh))).astype(np.int64), h - 1)
+        xi = np.minimum(np.floor(np.arange(ow, dtype=np.float32) * (np.float32(w) / np.float32(ow))).astype(np.int64), w - 1)
+        return T(a[:, yi][:, :, xi])
+    tf.image.resize_nearest_neighbor = resize_nearest_neighbor
+    base_softmax, base_where = tf.nn.softmax, tf.where
+    tf.nn.softmax = lambda x, axis=-1, name=None: base_softmax(x, name if isinstance(name, str) else None)
+    tf.nn.elu = lambda x, name=None: T(np.where(_np(x) > 0, _np(x), np.expm1(_np(x))))
+    tf.not_equal = lambda a, b, name=None: T(np.not_equal(_np(a), _np(b)))
+    tf.where = lambda c, x=None, y=None, name=None: base_where(c) if x is None else T(np.where(_np(c), _np(x), _np(y)))
+
+    def sparse_softmax_cross_entropy_with_logits(logits=None, labels=None, name=None):
+        a = _np(logits).astype(np.float32)
+        m = a.max(-1, keepdims=True)
+        lse = (m + np.log(np.exp(a - m).sum(-1, keepdims=True)))[..., 0]
+        return T((lse - np.take_along_axis(a, _np(labels)[..., None].astype(np.int64), -1)[..., 0]).astype(np.float32))
+    tf.nn.sparse_softmax_cross_entropy_with_logits = sparse_softmax_cross_entropy_with_logits
+    tf.reduce_sum = lambda x, axis=None, name=None: T(_np(x).sum(axis=tuple(axis) if isinstance(axis, list) else axis))
+    tf.unstack = lambda x, axis=0: [T(v) for v in np.moveaxis(_np(x), axis, 0)]
+
+    def py_func(f, inp, Tout, name=None):
+        res = [T(np.asarray(o)) for o in f(*[_np(i) for i in inp])]
+        for r in res:
+            r.set_shape = lambda shape: None
+        return res
+    tf.py_func = py_func
+    if not hasattr(np, "cast"):                       # numpy < 2 spelling used by core/Measures.py:66
+        np.cast = type("_Cast", (), {"__getitem__": lambda self, d: (lambda x: np.asarray(x, dtype=d))})()
+
+
 END_POINTS: Dict[str, T] = {}

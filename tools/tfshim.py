@@ -178,6 +178,7 @@ def _tf_module():
     tf.cast = lambda x, dtype, name=None: _named(T(_np(x).astype(dtype.np)), name)
     tf.to_float = lambda x, name=None: T(_np(x).astype(np.float32))
     tf.to_int32 = lambda x, name=None: T(_np(x).astype(np.int32))
+    tf.to_int32 = lambda x, name=None: T(_np(x).astype(np.int32))
     tf.shape = lambda x, name=None: T(np.array(_np(x).shape, np.int32))
     tf.size = lambda x, name=None: T(np.int32(_np(x).size))
     tf.reshape = lambda x, shape, name=None: _named(T(_np(x).reshape(_ints(shape))), name)
@@ -245,7 +246,7 @@ def _tf_module():
         idx = tuple(slice(b, None if s == -1 else b + s) for b, s in zip(_ints(begin), _ints(size)))
         return _named(T(a[idx]), name)
     tf.slice = slice_
-    tf.pad = lambda x, paddings, name=None: T(np.pad(_np(x), [tuple(p) for p in paddings]))
+    tf.pad = lambda x, paddings, name=None: T(np.pad(_np(x), [tuple(int(_np(v)) for v in p) for p in paddings]))
     tf.random_normal_initializer = tf.variance_scaling_initializer = tf.zeros_initializer = lambda *a, **k: None
 
     nn = types.ModuleType("tensorflow.nn")
@@ -436,8 +437,17 @@ def GlobalAvgPooling(x, data_format="NHWC"):
 
 
 @layer_register()
-def Deconv2D(x, *a, **k):
-    raise NotImplementedError("mask head is off in --forward (train.py:636-637)")
+def Deconv2D(x, out_shape, kernel_shape, stride, padding="SAME", W_init=None, b_init=None, nl=None, use_bias=True,
+             data_format="NHWC"):
+    """tensorpack Deconv2D = tf.nn.conv2d_transpose (the gradient of conv2d): W is [kh, kw, out_channel, in_channel]; with
+    SAME padding the output is in * stride.  Only the kernel == stride case the mask head uses (model.py:507) is restated:
+    y[n, o, s*i + a, s*j + b] = sum_c x[n, c, i, j] * W[a, b, o, c] + bias[o]."""
+    assert data_format == "NCHW" and isinstance(out_shape, int) and kernel_shape == stride and padding.upper() == "SAME"
+    cin = x.shape[1]
+    W = get_variable("W", (kernel_shape, kernel_shape, out_shape, cin))
+    b = get_variable("b", (out_shape,)) if use_bias else None
+    y = F.conv_transpose2d(_t(x), _t(W).permute(3, 2, 0, 1).contiguous(), None if b is None else _t(b), stride=stride)
+    return (nl or (lambda v, name=None: v))(T(y.numpy()), name="output")
 
 
 class _Anything(types.ModuleType):
