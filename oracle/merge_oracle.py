@@ -14,8 +14,12 @@ from their published algorithms:
     ((32-a)|a products * 32, sum 32768); BORDER_CONSTANT 0; value = (sum w*v + 2^14) >> 15.
   * COCO maskApi.c rleIou (iscrowd = 0): i = |A and B|, u = |A or B|, u = 1 when i == 0, iou = i/u in double;
     rleEncode / rleToBbox as in premvos_amd/rle.py (checked there).
-PARITY UNPINNED by the reference: it holds no test or golden vector for these functions and neither library can be
-imported here; the only pins are analytic cases (identity / integer-shift flows, hand-computed 2x2 IoU).
+PARITY: the reference holds no test or golden vector for these functions and neither library can be imported here.  The
+COMPOSITION is pinned since round 2 by executing merge_functions.py itself (tools/make_golden_merge.py: a recording cv2.remap
+keeps the sampling map the reference builds, integer-valued flows make bilinear == gather; dense-mask stand-ins for pycocotools):
+sign / grid of the warp, `== 1` binarisation, warp_proposals' keys and scores (tests/test_cpu_merge.py, HIP twin in
+tests/test_gpu_merge.py).  OpenCV's 1/32-pixel fixed-point interpolation and rleIou stay PARITY UNPINNED: restated from the
+published algorithms, analytic pins only (identity / integer-shift flows, quantisation and half-up cases, hand-computed IoUs).
 """
 from __future__ import annotations
 

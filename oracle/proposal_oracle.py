@@ -22,9 +22,14 @@ when IoU > thresh, boxes as given, area from min/max corners).  Where TF leaves 
 (top_k(sorted=False), equal scores in NMS) this oracle and the HIP path both use: descending score, ties to
 the lower index.
 
-PARITY UNPINNED by the reference: it holds no test or golden vector for this path.  The only in-repo
-known-answer is the 9-anchor table in the comments of utils/generate_anchors.py:20-38, which
-``generate_anchors`` below reproduces (tests/test_cpu_proposal.py).
+PARITY: the reference holds no test or golden vector for this path (its only in-repo known-answer is the 9-anchor table in
+the comments of utils/generate_anchors.py:20-38, reproduced by ``generate_anchors`` below, tests/test_cpu_proposal.py).
+PINNED since round 2 by fixtures produced by EXECUTING the reference's own python (config.py, data.py, common.py, eval.py,
+basemodel.py, model.py, train.py unmodified; tools/make_golden_tf.py on tools/tfshim.py, an eager stand-in for TF 1.8 /
+tensorpack): constants, the full anchor field, resize-shape math, all box arithmetic incl. ties, one whole inference pass of
+Model._build_graph (stage by stage, incl. the MODE_MASK branch), JSON rounding, checkpoint variable names
+(tests/test_cpu_proposal_ref.py; the HIP twin is tests/test_gpu_proposal_ref.py).  The TF primitives themselves (conv2d,
+fused batch norm, top_k, non_max_suppression, crop_and_resize, conv2d_transpose) remain restated: third-party, absent.
 """
 from __future__ import annotations
 

@@ -24,7 +24,13 @@ is restated from its published semantics:
 pycocotools (absent) RLE is restated from the COCO mask API spec: column-major runs starting with zeros,
 counts as delta-coded 5-bit groups + 48.
 
-PARITY UNPINNED by the reference: it ships no test or golden vector for this path.
+PARITY: the reference ships no test or golden vector for this path.  PINNED since round 2 by fixtures produced by EXECUTING
+the reference's own python (network/deeplab/{model,common}.py, core/{xception,feature_extractor}.py with DeepLabV3Plus.py's
+ModelOptions, network/SegmentationOutputLayers.py's eval branch, datasets/util/BoundingBox.py; tools/make_golden_deeplab.py on
+tools/slimshim.py, an eager stand-in for TF 1.8 + slim): block table, per-layer geometry, variable names, one whole pass of
+multi_scale_logits, frame-size mask / posterior of SegmentationSoftmax (tests/test_cpu_refinement_ref.py; HIP twin
+tests/test_gpu_refinement_ref.py).  slim conv / batch norm / resize primitives remain restated; COCO RLE (pycocotools, absent)
+is pinned only by its public spec and round trips.
 """
 from __future__ import annotations
 

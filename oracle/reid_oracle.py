@@ -15,7 +15,11 @@ Restated from (paths relative to code/ReID_net/):
   * export .............. Forwarding/ReIDForwarding.py:34-92 (proposal JSON gains "ReID": list of 128 floats)
 
 Third-party arithmetic (TensorFlow 1.x conv2d/max_pool SAME, resize_images, tf.round) is absent from this image and is
-restated from its published semantics.  PARITY UNPINNED by the reference: no test or golden vector exists for this path.
+restated from its published semantics.  PARITY: the reference holds no test or golden vector for this path; PINNED since round 2
+by fixtures produced by EXECUTING its own python (Config.py on configs/run, network/Network.py:build_tower instantiating
+NetworkLayers.py / NetworkOutputLayers.py, datasets/Similarity/DAVIS_Forward_Feed.py's crop pipeline; tools/make_golden_reid.py
+on tools/tfshim.py): layer table, every unit's wiring, variable names + shapes, whole-net activations and embedding, context
+boxes and crops (tests/test_cpu_reid_ref.py; HIP twin in tests/test_gpu_reid.py).  The TF primitives remain restated.
 """
 from __future__ import annotations
 

@@ -57,3 +57,28 @@ def test_warp_proposals_bookkeeping():
     assert out[0]["id"] == 7 and out[0]["score"] == 0.5 * 1.4 and out[0]["final_score"] == 0.4
     assert np.array_equal(rle.decode(out[0]["segmentation"]), out[0]["mask"])
     assert out[0]["bbox"] == rle.to_bbox(rle.encode(out[0]["mask"]))
+
+
+def test_oracle_vs_reference_executed_warp_proposals():
+    """tests/golden/merge_ref.npz: MergeTrack/merge_functions.py's get_flow / warp_flow / warp_proposals EXECUTED by
+    tools/make_golden_merge.py with a recording cv2.remap (integer-valued flows: bilinear == gather) and dense-mask stand-ins for
+    pycocotools.  Pins the sampling map (-flow + grid), `== 1` binarisation and warp_proposals' bookkeeping."""
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = np.load(os.path.join(gold, "merge_ref.npz"))
+    hr = json.load(open(os.path.join(gold, "merge_host_refs.json")))
+    assert hr["interpolation_flag_is_INTER_LINEAR"] and hr["remap_calls"] == len(ref["masks"]) and hr["segmentation_counts_is_str"]
+    flow = ref["flow"]
+    assert np.array_equal(M.remap_map(flow), ref["remap_map"])
+    for m, want in zip(ref["masks"], ref["warped_masks"]):
+        assert np.array_equal(M.warp_flow(m, flow), want)
+    assert np.array_equal(M.warp_flow(ref["grey"], flow, binarize=False), ref["grey_warped"])
+    assert np.array_equal(M.warp_flow(ref["grey"], flow), ref["grey_warped_bin"])
+    props = [{"mask": m, "id": w["id"], "final_score": w["final_score"], "object_score": w["object_score"]}
+             for m, w in zip(ref["masks"], hr["warped"])]
+    out = M.warp_proposals(props, flow, rle)
+    assert sorted(out[0].keys()) == hr["warped_keys"]
+    for o, w, bb in zip(out, hr["warped"], ref["warped_bbox"]):
+        assert o["score"] == w["score"] and o["id"] == w["id"] and o["final_score"] == w["final_score"]
+        assert np.array_equal(np.asarray(o["bbox"], np.float64), bb)

@@ -1,0 +1,78 @@
+"""oracle/reid_oracle.py and the product's host arithmetic against fixtures produced by EXECUTING the reference's ReID_net python
+(tools/make_golden_reid.py: Config.py on configs/run, network/Network.py:build_tower instantiating NetworkLayers.py /
+NetworkOutputLayers.py layer by layer, datasets/Similarity/DAVIS_Forward_Feed.py's crop pipeline -- all unmodified, on
+tools/tfshim.py's eager stand-in for TF 1.x).  Pins: the layer table of configs/run, the wiring / strides / BatchNorm placement
+of every unit, checkpoint variable names + shapes, the float32 context-region arithmetic, crop / resize / normalise order.  The
+TF primitives themselves (conv2d / max_pool SAME, batch_normalization, resize_images, round) are restated in the stand-in."""
+import json
+import os
+
+import numpy as np
+
+from oracle import reid_oracle as R
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HR = json.load(open(os.path.join(GOLD, "reid_host_refs.json")))
+REF = np.load(os.path.join(GOLD, "reid_ref.npz"))
+SEED, N = 5, 3
+
+
+def ref_input():
+    x = np.random.default_rng(SEED).standard_normal((N, 128, 128, 3)).astype(np.float32)
+    assert abs(float(x.astype(np.float64).sum()) - REF["input_checksum"][0]) < 1e-6
+    return x
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max() <= tol * max(1.0, float(np.abs(b).max()))
+
+
+def test_layer_table_of_configs_run():
+    names = [u[0] for u in R.UNITS]
+    assert HR["layer_order"] == ["conv0"] + names + ["conv1", "fc1", "fc2", "outputTriplet"]
+    assert HR["config"] == {"input_size": [R.INPUT_SIZE, R.INPUT_SIZE], "num_classes": R.EMBED, "context_region_factor": R.CONTEXT,
+                            "output_embedding_layer": "outputTriplet"}
+    # the product's table is the same one
+    from premvos_amd.reid import model as PM
+    assert [(n, tuple(f), tuple(k), tuple(s)) for n, f, k, s in PM.UNITS] == [(n, tuple(f), tuple(k), tuple(s)) for n, _, f, k, s in R.UNITS]
+
+
+def test_whole_net_oracle_vs_reference_build_tower():
+    w = R.synth_weights(SEED)
+    inter = {}
+    emb = R.forward(w, ref_input(), intermediates=inter)
+    for name, shape in HR["layer_shapes"].items():
+        if name in inter:                                                   # NCHW here, NHWC there
+            a = inter[name].permute(0, 2, 3, 1).numpy()
+            assert list(a.shape) == shape, name
+            assert _close(a[:, ::3, ::3, ::32], REF["act_" + name], 1e-4), name
+    assert HR["layer_shapes"]["outputTriplet"] == [N, R.EMBED]
+    assert _close(emb, REF["embedding"], 1e-4)
+    assert _close(emb, REF["act_outputTriplet"], 1e-4)
+
+
+def test_variable_names_the_graph_requests_are_the_importers():
+    from premvos_amd import weights as W
+    w = R.synth_weights(SEED)
+    tfv = W.reid_weights_to_tf(w)
+    req = {n: tuple(s) for n, s in HR["variables"]}
+    assert sorted(req) == sorted(tfv)
+    assert all(tuple(tfv[n].shape) == s for n, s in req.items())
+    back = W.reid_weights_from_tf({n: tfv[n] for n in req})
+    assert sorted(back) == sorted(w)
+
+
+def test_crop_pipeline_oracle_and_product_vs_reference_feed_dataset():
+    frame, boxes = REF["crop_frame"], REF["crop_boxes_xywh"]
+    h, w = frame.shape[:2]
+    ctx = R.context_boxes(boxes, h, w, feed=True)
+    assert np.array_equal(ctx, REF["crop_context_boxes"].astype(np.int32))
+    from premvos_amd.reid import context_boxes
+    assert np.array_equal(context_boxes(boxes, h, w, True), ctx)
+    crops = np.stack([R.make_crop(frame, b, feed=True) for b in ctx])
+    assert np.abs(crops[:, ::3, ::3] - REF["crops_sub"]).max() < 2e-6
+    assert np.abs(crops.mean(axis=(1, 2), dtype=np.float64) - REF["crops_mean"]).max() < 1e-5
+    small = [i for i, b in enumerate(ctx) if min(b[2], b[3]) <= 10]
+    assert small, "the fixture holds a box under the 10-pixel rule"

@@ -158,3 +158,26 @@ def test_warp_proposals_with_resident_masks():
         assert a["segmentation"] == b["segmentation"] and a["bbox"] == b["bbox"] and a["score"] == b["score"]
     again = MT.warp_proposals(dev, torch.from_numpy(f).cuda(), device_masks=True)          # the result feeds the next frame
     assert len(again) == 3 and again[0]["mask"].is_cuda
+
+
+def test_mask_warp_vs_reference_executed_warp_proposals():
+    """The HIP mask warp + warp_proposals against tests/golden/merge_ref.npz (merge_functions.py executed by
+    tools/make_golden_merge.py; see tests/test_cpu_merge.py for what that pins)."""
+    import json
+    import os
+    from premvos_amd import mergetrack as MT
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = np.load(os.path.join(gold, "merge_ref.npz"))
+    hr = json.load(open(os.path.join(gold, "merge_host_refs.json")))
+    flow = ref["flow"]
+    assert np.array_equal(MT.warp_masks(ref["masks"], flow).cpu().numpy(), ref["warped_masks"])
+    assert np.array_equal(MT.warp_flow(ref["grey"], flow, binarize=False), ref["grey_warped"])
+    assert np.array_equal(MT.warp_flow(ref["grey"], flow), ref["grey_warped_bin"])
+    props = [{"mask": m, "id": w["id"], "final_score": w["final_score"], "object_score": w["object_score"]}
+             for m, w in zip(ref["masks"], hr["warped"])]
+    out = MT.warp_proposals(props, flow)
+    assert sorted(out[0].keys()) == hr["warped_keys"]
+    for o, w, bb, wm in zip(out, hr["warped"], ref["warped_bbox"], ref["warped_masks"]):
+        assert o["score"] == w["score"] and o["id"] == w["id"] and o["object_score"] == w["object_score"]
+        assert np.array_equal(np.asarray(o["bbox"], np.float64), bb) and np.array_equal(np.asarray(o["mask"]), wm)
+        assert isinstance(o["segmentation"]["counts"], str)

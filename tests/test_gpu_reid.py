@@ -120,3 +120,38 @@ def test_driver_json_contract(tmp_path):
     cb = R.context_boxes([rle.to_bbox(bprops[0]["segmentation"])], 100, 160, feed=False)
     ref = R.forward(w, np.stack([R.make_crop(jpg, cb[0], feed=False)]), SMALL_O)
     assert np.abs(np.array(res[0]["ReID"]) - ref[0]).max() < 1e-3 * max(1.0, np.abs(ref).max())
+
+
+def test_full_depth_net_and_crops_vs_reference_executed_fixture():
+    """The HIP ReID path against tests/golden/reid_ref.npz -- the reference's own Network.build_tower / DAVIS_Forward_Feed code
+    executed by tools/make_golden_reid.py (tests/test_cpu_reid_ref.py says what that pins)."""
+    import os
+    from premvos_amd import _lib
+    from premvos_amd.reid import ReIDNet, context_boxes
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = np.load(os.path.join(gold, "reid_ref.npz"))
+    x = np.random.default_rng(5).standard_normal((3, 128, 128, 3)).astype(np.float32)
+    assert abs(float(x.astype(np.float64).sum()) - ref["input_checksum"][0]) < 1e-6
+    net = ReIDNet(R.synth_weights(5), use_graph=False)
+    p = net.plan(3, 96, 150, True)
+    p.net_in.buf[..., :3] = torch.from_numpy(x).cuda()
+    for _, fn in p.steps[1:]:                        # everything after the crop kernel: the net on the fixture's input
+        fn()
+    torch.cuda.synchronize()
+    for name in ("res0", "res5", "res11", "res14", "res15", "res16"):
+        g = p.unit_out[name].torch().cpu().permute(0, 2, 3, 1).numpy()[:, ::3, ::3, ::32]
+        want = ref["act_" + name]
+        assert g.shape == want.shape and np.abs(g - want).max() < 1e-3 * max(1.0, np.abs(want).max()), name
+    emb = p.embeddings.cpu().numpy()
+    assert np.abs(emb - ref["embedding"]).max() < 1e-3 * max(1.0, np.abs(ref["embedding"]).max())
+    # crops: DAVISForwardFeedDataset._create_inputs_for_eval
+    frame, boxes = ref["crop_frame"], ref["crop_boxes_xywh"]
+    cb = context_boxes(boxes, 96, 150, True)
+    assert np.array_equal(cb, ref["crop_context_boxes"].astype(np.int32))
+    out = torch.zeros((len(cb), 128, 128, 4), device="cuda")
+    dimg, dcb = torch.from_numpy(frame).cuda(), torch.from_numpy(cb).cuda()
+    _lib.check(_lib.load().premvos_reid_input_u8(dimg.data_ptr(), 96, 150, dcb.data_ptr(), len(cb), 128, 1, out.data_ptr(),
+                                                 _lib.current_stream()), "reid_input")
+    got = out.cpu().numpy()[..., :3]
+    assert np.abs(got[:, ::3, ::3] - ref["crops_sub"]).max() < 3e-6
+    assert np.abs(got.mean(axis=(1, 2), dtype=np.float64) - ref["crops_mean"]).max() < 1e-5

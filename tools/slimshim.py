@@ -213,7 +213,13 @@ def install_output_layer_api(tf):
               "tensorflow.python.layers", "tensorflow.python.layers.utils"):
         sys.modules[n] = tfshim._Anything(n)
         sys.modules[n].__path__ = []
-    tf.image.resize_images = lambda images, size, method=0, align_corners=False: resize_bilinear(images, size, align_corners)
+
+    def resize_images(images, size, method=0, align_corners=False):
+        """tf.image.resize_images (bilinear): 3-D input is one image (expanded and squeezed again)."""
+        if len(_np(images).shape) == 3:
+            return T(_np(resize_bilinear(T(_np(images)[None]), size, align_corners))[0])
+        return resize_bilinear(images, size, align_corners)
+    tf.image.resize_images = resize_images
 
     def resize_nearest_neighbor(images, size, align_corners=False, name=None):
         """TF1 legacy: src = min(floor(dst * in / out), in - 1), the scale and the product in float32."""

@@ -183,7 +183,7 @@ def _tf_module():
     tf.size = lambda x, name=None: T(np.int32(_np(x).size))
     tf.reshape = lambda x, shape, name=None: _named(T(_np(x).reshape(_ints(shape))), name)
     tf.transpose = lambda x, perm=None, name=None: T(np.transpose(_np(x), perm))
-    tf.squeeze = lambda x, axis=None, name=None: T(np.squeeze(_np(x), axis=axis))
+    tf.squeeze = lambda x, axis=None, name=None: T(np.squeeze(_np(x), axis=tuple(axis) if isinstance(axis, list) else axis))
     tf.expand_dims = lambda x, axis, name=None: T(np.expand_dims(_np(x), axis))
     tf.tile = lambda x, multiples, name=None: T(np.tile(_np(x), _ints(multiples)))
     tf.stack = lambda vals, axis=0, name=None: T(np.stack([_np(v) for v in vals], axis))
@@ -236,6 +236,9 @@ def _tf_module():
     tf.sparse_to_dense = sparse_to_dense
 
     def map_fn(f, elems, dtype=None, parallel_iterations=None):
+        if not isinstance(elems, (tuple, list)):                    # a single tensor: f takes its rows
+            rows = [_np(f(T(r))) for r in _np(elems)]
+            return T(np.stack(rows)) if rows else T(np.zeros((0,), (dtype or float32).np))
         n = len(_np(elems[0]))
         return T(np.stack([_np(f(tuple(T(_np(e)[i]) for e in elems))) for i in range(n)])) if n else T(np.zeros((0,), dtype.np))
     tf.map_fn = map_fn
