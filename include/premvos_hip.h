@@ -84,13 +84,16 @@ typedef struct premvos_conv_desc {
   int32_t out_mode;     /* PREMVOS_OUT_*   */
   int32_t cout_ps;      /* PIXSHUF2: channels per phase (cout == 4*cout_ps); out dims are 2ho x 2wo */
   int32_t tile_hint;    /* 0 = auto; (BM<<16)|BN forces an MFMA tile config; 1 forces the direct kernel for cout <= 2;  */
-                        /* 2 = Winograd F(2x2,3x3) (csrc/conv_wino_f32.hip; needs wgt_wino)                             */
+                        /* 2 = Winograd F(2x2,3x3) (csrc/conv_wino_f32.hip; needs wgt_wino), 16 component slabs in the  */
+                        /* workspace + an output-transform launch; 3 = the same algebra in ONE kernel without workspace */
+                        /* (a workgroup walks all 16 components of its block; output transform from registers)          */
   int32_t split_k;      /* 0 = auto, <0 = never, >0 = force this many k-slices */
   float* workspace;     /* split-K partial slabs (may be NULL: then never split) */
   int64_t workspace_bytes;
   int32_t precision;    /* PREMVOS_PREC_*; bf16 modes: wgt = bf16 hi [cout_pad][k_pad], k_pad % 32 == 0 */
   int32_t stage_k;      /* fp32 path: k depth of an LDS stage, 16 or 32 (0 = library default); with tile_hint == 2: 64 = 64 */
-                        /* instead of 128 tile rows per workgroup                                                  */
+                        /* instead of 128 tile rows per workgroup; with tile_hint == 3: the block (2x2-tile rows x      */
+                        /* couts / waves / stage depth) of a workgroup: 0, 2..6 (table in csrc/conv_wino_f32.hip)       */
   const void* wgt_lo;   /* BF16X3: bf16 low parts (w - float(hi)), same shape as wgt */
   int32_t tail_m_tiles; /* fp32 path, unsplit layers: the last tail_m_tiles rows of BM-tall output tiles are computed  */
   int32_t tail_split_k; /* as tail_split_k k-slices + fixed-order reduce (fills a partly empty last wave); 0 = off    */

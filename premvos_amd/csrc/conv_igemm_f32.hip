@@ -302,6 +302,7 @@ namespace premvos {
 bool conv_wino_applicable(const premvos_conv_desc& d);        // conv_wino_f32.hip
 long conv_wino_workspace_bytes(const premvos_conv_desc& d);
 int conv_wino(const premvos_conv_desc& d, hipStream_t s);
+int conv_wino_fused(const premvos_conv_desc& d, hipStream_t s);
 bool conv_smalln_applicable(const premvos_conv_desc& d);      // conv_smalln_f32.hip
 int conv_smalln(const premvos_conv_desc& d, hipStream_t s);
 int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin) {
@@ -489,6 +490,11 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
                "symmetric padding and packed filter transforms (wgt_wino)");
     return premvos::conv_wino(d, s);
   }
+  if (d.tile_hint == 3) {      // ... the slab-free variant of it (no workspace, one kernel); stage_k = block id
+    PV_REQUIRE(premvos::conv_wino_applicable(d), "conv2d: Winograd needs a 3x3 / stride 1 / dilation 1 fp32 layer with cout %% 4 == 0, "
+               "symmetric padding and packed filter transforms (wgt_wino)");
+    return premvos::conv_wino_fused(d, s);
+  }
   // 1- and 2-channel heads: per-pixel dot products, not GEMM tiles (tile_hint 0 = auto, 1 = forced; any other hint
   // keeps them on the MFMA kernel, which is what the autotuner compares against)
   if ((d.tile_hint == 0 || d.tile_hint == 1) && premvos::conv_smalln_applicable(d)) return premvos::conv_smalln(d, s);
@@ -519,6 +525,7 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   if (dp == nullptr || dp->k_pad <= 0 || dp->n <= 0 || dp->ho <= 0 || dp->wo <= 0 || dp->cout <= 0) return 0;
   if (dp->precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16_workspace_bytes(*dp);
   if (dp->tile_hint == 2) return premvos::conv_wino_applicable(*dp) ? premvos::conv_wino_workspace_bytes(*dp) : 0;
+  if (dp->tile_hint == 3) return 0;
   if ((dp->tile_hint == 0 || dp->tile_hint == 1) && premvos::conv_smalln_applicable(*dp)) return 0;
   int bm, bn;
   pick_tile(*dp, &bm, &bn);

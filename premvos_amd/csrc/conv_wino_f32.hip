@@ -190,6 +190,247 @@ __global__ __launch_bounds__(256, 3) void wino_gemm_kernel(const premvos_conv_de
   }
 }
 
+// A^T of F(2x2,3x3): output row a of a tile takes component row xi with weight W_AT[a][xi]
+__device__ __constant__ float W_AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+
+// The slab-free variant: one workgroup owns a (BM tiles x BN couts) block for ALL 16 components.  It walks the components one
+// after the other through the same double-buffered K loop (16 * KT stages, the prefetch runs across component boundaries), keeps
+// the raw product of the current component in one set of MFMA accumulators and, at the end of each component, adds it with its
+// A^T (x) A^T weight (0 / +1 / -1) into the four output-pixel accumulators of the 2x2 tile.  Bias, residual and activation are
+// applied from registers and the 2x2 pixels are written once: no workspace, no second kernel, no 16x slab round trip.  The price
+// is registers (4 + 1 accumulator sets), so the per-wave tile is 64x32 / 32x64 and two waves share a SIMD.
+template <int BM, int BN, int WM, int WN, int KB>
+__global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premvos_conv_desc p, const float* __restrict__ wgt_wino,
+                                                                     const int tiles_y, const int tiles_x, const int m_tiles,
+                                                                     const int n_tiles) {
+  constexpr int NT = 64 * WM * WN, RS = KB + 4, KU = KB / 4;      // (shadow the file-scope 16-deep stage constants)
+  constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
+  constexpr int A_PER_T = BM * KU / NT, B_PER_T = (BN * KU + NT - 1) / NT;
+  constexpr int BUF = (BM + BN) * RS;
+  static_assert(BM * KU % NT == 0 && A_PER_T >= 1, "staging must divide evenly");
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  float(*lds)[BUF] = reinterpret_cast<float(*)[BUF]>(lds_dyn);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
+  const int tpi = tiles_y * tiles_x;
+  const int Mt = p.n * tpi;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    tile_n = v % n_tiles;
+    tile_m = v / n_tiles;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int j4 = (tid % KU) * 4;
+
+  // per staged row: element offset of the 4x4 patch origin and which of its rows / columns lie inside the image
+  long boff[A_PER_T];
+  unsigned vy[A_PER_T], vx[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int m = m0 + (tid / KU) + i * (NT / KU);
+    const bool rok = m < Mt;
+    const int mm = rok ? m : 0;
+    const int n = mm / tpi, rem = mm - n * tpi;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int y0 = 2 * ty - p.pt, x0 = 2 * tx - p.pl;
+    boff[i] = (((long)n * p.h + y0) * p.w + x0) * p.in_ps;
+    vy[i] = vx[i] = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      vy[i] |= (rok && (unsigned)(y0 + t) < (unsigned)p.h) ? 1u << t : 0u;
+      vx[i] |= ((unsigned)(x0 + t) < (unsigned)p.w) ? 1u << t : 0u;
+    }
+  }
+  unsigned wbase[B_PER_T];                   // element offsets (the launcher refuses tensors past 2^30 elements)
+  bool wok[B_PER_T];
+#pragma unroll
+  for (int i = 0; i < B_PER_T; ++i) {
+    const int row = (tid / KU) + i * (NT / KU);
+    wok[i] = row < BN && n0 + row < p.cout_pad;
+    wbase[i] = (unsigned)(wok[i] ? n0 + row : 0) * p.k_pad + j4;
+  }
+  const unsigned wcomp = (unsigned)p.cout_pad * p.k_pad;
+
+  // the component being staged
+  unsigned src[A_PER_T][4];
+  unsigned okm[A_PER_T];
+  unsigned wrow[B_PER_T];
+  float si = 0.f, sj = 0.f;
+  auto set_comp = [&](int comp) {
+    const int xi = comp >> 2, nu = comp & 3;
+    const int ia[2] = {W_I1[xi], W_I2[xi]}, jb[2] = {W_I1[nu], W_I2[nu]};
+    si = W_S2[xi];
+    sj = W_S2[nu];
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      okm[i] = 0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const bool in = ((vy[i] >> ia[a]) & 1u) && ((vx[i] >> jb[b]) & 1u);
+          okm[i] |= in ? 1u << (a * 2 + b) : 0u;
+          src[i][a * 2 + b] = in ? (unsigned)(boff[i] + ((long)ia[a] * p.w + jb[b]) * p.in_ps) : 0u;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) wrow[i] = wbase[i] + comp * wcomp;
+  };
+
+  float4 ra[A_PER_T][4], rb[B_PER_T];
+  auto gload = [&](int kt) {
+    const int c = kt * KB + j4;
+    const int cc = c < p.cin_pad ? c : 0;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ra[i][t] = *reinterpret_cast<const float4*>(p.in + (size_t)(src[i][t] + (unsigned)cc));
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i)
+      rb[i] = *reinterpret_cast<const float4*>(wgt_wino + (size_t)(wrow[i] + (unsigned)(c < p.k_pad ? kt * KB : 0)));
+  };
+  auto lstore = [&](int buf, int kt) {
+    const bool kok = kt * KB + j4 < p.cin_pad;
+    float* a = &lds[buf][0];
+    float* b = &lds[buf][BM * RS];
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int row = (tid / KU) + i * (NT / KU);
+      const float4 d11 = sel4(kok && (okm[i] & 1u), ra[i][0]), d12 = sel4(kok && (okm[i] & 2u), ra[i][1]);
+      const float4 d21 = sel4(kok && (okm[i] & 4u), ra[i][2]), d22 = sel4(kok && (okm[i] & 8u), ra[i][3]);
+      float4 v;
+      v.x = (d11.x + sj * d12.x) + si * (d21.x + sj * d22.x);
+      v.y = (d11.y + sj * d12.y) + si * (d21.y + sj * d22.y);
+      v.z = (d11.z + sj * d12.z) + si * (d21.z + sj * d22.z);
+      v.w = (d11.w + sj * d12.w) + si * (d21.w + sj * d22.w);
+      *reinterpret_cast<float4*>(a + row * RS + j4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int row = (tid / KU) + i * (NT / KU);
+      if (BN * KU % NT == 0 || row < BN) *reinterpret_cast<float4*>(b + row * RS + j4) = sel4(wok[i] && kt * KB + j4 < p.k_pad, rb[i]);
+    }
+  };
+
+  f32x16 M[MT][NTL], Y[2][2][MT][NTL];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        M[mi][ni][r] = 0.f;
+        Y[0][0][mi][ni][r] = Y[0][1][mi][ni][r] = Y[1][0][mi][ni][r] = Y[1][1][mi][ni][r] = 0.f;
+      }
+
+  const int KT = (p.k_pad + KB - 1) / KB;
+  const int total = 16 * KT;
+  set_comp(0);
+  gload(0);
+  lstore(0, 0);
+  __syncthreads();
+  const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  int comp_c = 0, kt_c = 0, comp_n = 0, kt_n = 0;            // the stage being multiplied / the stage being staged
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    const bool has_next = it + 1 < total;
+    if (has_next) {
+      if (++kt_n == KT) {
+        kt_n = 0;
+        set_comp(++comp_n);
+      }
+      gload(kt_n);
+    }
+    const float* a = &lds[buf][wm0 * RS + frag_off];
+    const float* b = &lds[buf][(BM + wn0) * RS + frag_off];
+#pragma unroll
+    for (int h = 0; h < KB / 8; ++h) {
+      // the next stage goes to LDS half way through this one: its ds_writes retire under the remaining MFMAs
+      if (h == KB / 16 && has_next) lstore(buf ^ 1, kt_n);
+      float4 af[MT], bf[NTL];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni) {
+          M[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, M[mi][ni], 0, 0, 0);
+          M[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, M[mi][ni], 0, 0, 0);
+          M[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, M[mi][ni], 0, 0, 0);
+          M[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, M[mi][ni], 0, 0, 0);
+        }
+    }
+    if (++kt_c == KT) {                      // component finished: Y[a][b] += A^T[a][xi] * A^T[b][nu] * M
+      const float ca[2] = {W_AT[0][comp_c >> 2], W_AT[1][comp_c >> 2]}, cb[2] = {W_AT[0][comp_c & 3], W_AT[1][comp_c & 3]};
+#pragma unroll
+      for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+        for (int yb = 0; yb < 2; ++yb) {
+          const float c = ca[ya] * cb[yb];
+          if (c != 0.f) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[ya][yb][mi][ni][r] += c * M[mi][ni][r];
+          }
+        }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) M[mi][ni][r] = 0.f;
+      kt_c = 0;
+      ++comp_c;
+    }
+    __syncthreads();
+  }
+
+  // bias + residual + activation, the 2x2 pixels of every tile row this lane holds
+  float bv[NTL];
+  int cols[NTL];
+#pragma unroll
+  for (int ni = 0; ni < NTL; ++ni) {
+    cols[ni] = n0 + wn0 + ni * 32 + (lane & 31);
+    bv[ni] = (p.bias != nullptr && cols[ni] < p.cout) ? p.bias[cols[ni]] : 0.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= Mt) continue;
+      const int n = m / tpi, rem = m - n * tpi;
+      const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+      for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+        for (int yb = 0; yb < 2; ++yb) {
+          const int oy = 2 * ty + ya, ox = 2 * tx + yb;
+          if (oy >= p.ho || ox >= p.wo) continue;
+          const long pix = ((long)n * p.ho + oy) * p.wo + ox;
+#pragma unroll
+          for (int ni = 0; ni < NTL; ++ni) {
+            if (cols[ni] >= p.cout) continue;
+            float v = Y[ya][yb][mi][ni][r] + bv[ni];
+            if (p.res != nullptr) v += p.res[pix * p.res_ps + cols[ni]];
+            if (p.act == PREMVOS_ACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (p.act == PREMVOS_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+            else if (p.act == PREMVOS_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            p.out[pix * p.out_ps + cols[ni]] = v;
+          }
+        }
+    }
+}
+
 // Y = A^T M A per (tile, 4 couts), A^T = [[1,1,1,0],[0,1,-1,-1]], + bias + residual + activation -> the tile's 2x2 pixels.
 __global__ __launch_bounds__(256) void wino_output_kernel(const premvos_conv_desc p, const float* __restrict__ ws,
                                                           const int tiles_y, const int tiles_x, const int ncols) {
@@ -289,6 +530,43 @@ static int launch_wino(const premvos_conv_desc& d, hipStream_t s) {
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(wino_output_kernel, dim3(g), dim3(256), 0, s, d, d.workspace, ty, tx, n_tiles * BN);
   return check_launch("wino_output");
+}
+
+template <int BM, int BN, int WM, int WN, int KB>
+static int launch_wino_fused(const premvos_conv_desc& d, hipStream_t s) {
+  const int ty = (d.ho + 1) / 2, tx = (d.wo + 1) / 2;
+  const long mt = (long)d.n * ty * tx;
+  premvos_conv_desc w = d;
+  w.k_pad = cdiv((int)d.cin_pad, 16) * 16;              // (a 32-deep stage zero-fills past it)
+  const int m_tiles = cdiv((int)mt, BM), n_tiles = cdiv(d.cout, BN);
+  constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<BM, BN, WM, WN, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wino_fused_kernel<BM, BN, WM, WN, KB>), dim3(m_tiles * n_tiles), dim3(64 * WM * WN), LDS_BYTES, s, w, d.wgt_wino, ty, tx,
+                     m_tiles, n_tiles);
+  return check_launch("wino_fused");
+}
+
+// tile_hint 3: the slab-free kernel; stage_k picks the block (tile rows x couts / waves / stage depth): 0 = 128x128 / 8 / 16,
+// 2 = 64x128 / 4 / 16, 3 = 64x64 / 4 / 16, 4 = 64x128 / 4 / 32, 5 = 64x64 / 4 / 32, 6 = 128x128 / 8 / 32 (measured and dropped:
+// 128x64 / 4 / 16, 128x32 / 4 / 32, 128x64 / 8 / 32 -- never the fastest on the pipeline's layers)
+int conv_wino_fused(const premvos_conv_desc& d, hipStream_t s) {
+  if ((long)d.n * ((d.ho + 1) / 2) * ((d.wo + 1) / 2) >= (1L << 27)) return fail(PREMVOS_EINVAL, "conv2d(winograd): too many tiles");
+  if ((long)d.n * d.h * d.w * d.in_ps >= (1L << 30) || 16L * d.cout_pad * (cdiv((int)d.cin_pad, 16) * 16) >= (1L << 30))
+    return fail(PREMVOS_EINVAL, "conv2d(winograd, fused): 32-bit operand offsets need tensors below 2^30 elements");
+  switch (d.stage_k) {
+    case 0: return launch_wino_fused<128, 128, 2, 4, 16>(d, s);
+    case 2: return launch_wino_fused<64, 128, 2, 2, 16>(d, s);
+    case 3: return launch_wino_fused<64, 64, 2, 2, 16>(d, s);
+    case 4: return launch_wino_fused<64, 128, 2, 2, 32>(d, s);
+    case 5: return launch_wino_fused<64, 64, 2, 2, 32>(d, s);
+    case 6: return launch_wino_fused<128, 128, 2, 4, 32>(d, s);
+    default: return fail(PREMVOS_EINVAL, "conv2d(winograd, fused): stage_k %d is not a block id (0, 2..6)", d.stage_k);
+  }
 }
 
 int conv_wino(const premvos_conv_desc& d, hipStream_t s) {

@@ -6,6 +6,7 @@ libpremvos_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -259,6 +260,10 @@ def _candidates(d: ConvDesc):
         out.append((2, 0, -1, 0, 0))               # tile_hint 2 = Winograd F(2x2,3x3) (csrc/conv_wino_f32.hip), 128 tile rows
         if d.cout > 32:
             out.append((2, 64, -1, 0, 0))          # ... with 64-tile-row workgroups
+        # tile_hint 3 = the same algebra without slabs: one kernel, a workgroup walks all 16 components of its block
+        # (stage_k = block id, see conv_wino_f32.hip: tile rows x couts / waves / stage depth)
+        if os.environ.get("PREMVOS_WINOGRAD_FUSED", "1") != "0":
+            out.extend((3, v, -1, 0, 0) for v in (() if d.cout <= 32 else (3, 5) if d.cout <= 64 else (0, 2, 4, 6)))
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((128, 128), (128, 64), (64, 128))) else [16]

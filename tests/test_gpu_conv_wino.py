@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+FUSED = (0, 2, 3, 4, 5, 6)            # block ids of the slab-free Winograd kernel (tile_hint 3, stage_k)
 
 
 def _ops():
@@ -41,10 +42,12 @@ def test_winograd_matches_torch_and_the_gemm_kernel(n, cin, cout, h, w, act, res
     xin = _nhwc(x, ops, ps=(cin + 3) // 4 * 4 + 8, coff=4)
     rin = _nhwc(r, ops) if res else None
     outs = {}
-    for tag, hint in (("wino", 2), ("gemm", (128 << 16) | (128 if cout > 64 else 64 if cout > 32 else 32))):
+    cases = [("wino", 2, 0), ("gemm", (128 << 16) | (128 if cout > 64 else 64 if cout > 32 else 32), 0)]
+    cases += [(f"fused{v}", 3, v) for v in FUSED]               # the slab-free kernel, every block / stage depth
+    for tag, hint, stage_k in cases:
         out = ops.NHWC.alloc(n, h, w, cout + 8)
         out.buf.fill_(3.0)
-        ops.conv2d(xin, pk, out.slice(4, cout), pad=(1, 1), act=a, res=rin, tile_hint=hint)
+        ops.conv2d(xin, pk, out.slice(4, cout), pad=(1, 1), act=a, res=rin, tile_hint=hint, stage_k=stage_k)
         torch.cuda.synchronize()
         assert torch.all(out.buf[..., :4] == 3.0) and torch.all(out.buf[..., 4 + cout:] == 3.0)      # window respected
         outs[tag] = out.slice(4, cout).torch().cpu().double()
@@ -52,6 +55,10 @@ def test_winograd_matches_torch_and_the_gemm_kernel(n, cin, cout, h, w, act, res
     assert (outs["gemm"] - ref).abs().max().item() < 2e-5 * scale
     assert (outs["wino"] - ref).abs().max().item() < 5e-5 * scale            # Winograd rounding: sums before the products
     assert (outs["wino"] - outs["gemm"]).abs().max().item() < 5e-5 * scale
+    for v in FUSED:
+        assert (outs[f"fused{v}"] - ref).abs().max().item() < 5e-5 * scale, v
+        # same products, same K order; only the order of the sixteen component sums differs from the slab version
+        assert (outs[f"fused{v}"] - outs["wino"]).abs().max().item() < 2e-5 * scale, v
 
 
 def test_winograd_is_refused_where_it_does_not_apply():
@@ -62,5 +69,10 @@ def test_winograd_is_refused_where_it_does_not_apply():
     out = ops.NHWC.alloc(1, 4, 4, 16)
     with pytest.raises(_lib.PremvosError, match="Winograd"):
         ops.conv2d(x, pk, out, stride=(2, 2), pad=(1, 1), tile_hint=2)          # stride 2
+    with pytest.raises(_lib.PremvosError, match="Winograd"):
+        ops.conv2d(x, pk, out, stride=(2, 2), pad=(1, 1), tile_hint=3)
+    out1 = ops.NHWC.alloc(1, 8, 8, 16)
+    with pytest.raises(_lib.PremvosError, match="block id"):
+        ops.conv2d(x, pk, out1, pad=(1, 1), tile_hint=3, stage_k=11)
     pk1 = ops.pack_conv(torch.randn((16, 16, 1, 1)), None)
     assert pk1.wgt_wino is None

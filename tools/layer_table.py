@@ -20,7 +20,7 @@ for _ in range(5):
     for i, (a, b) in enumerate(evs): samples[i].append(a.elapsed_time(b))
 rows = []
 for (st, name, fn, fl, _, d), sm in zip(items, samples):
-    name = name + (" [winograd]" if d.tile_hint == 2 else "")
+    name = name + (" [winograd]" if d.tile_hint == 2 else f" [winograd, slab-free {d.stage_k}]" if d.tile_hint == 3 else "")
     ms = sorted(sm)[2]; mult = pipe.refine_calls_per_step if st == "refine" else 1
     per = fl / mult
     rows.append((ms * mult - fl / 120e9, st, name, ms, per / ms / 1e9, mult))
@@ -35,6 +35,10 @@ for l, st, name, ms, tf, mult in rows:
     agg[key][0] += l; agg[key][1] += ms * mult
 for k, (l, t) in sorted(agg.items(), key=lambda x: -x[1][0])[:30]:
     print(f"  lost {l:7.2f} ms  time {t:7.2f} ms  {k}")
+print("3x3 stride-1 layers (Winograd candidates):")
+for l, st, name, ms, tf, mult in rows:
+    if "winograd" in name:
+        print(f"  {ms*1e3:8.1f} us x{mult}  {tf:6.1f} TF/s  {st}:{name}")
 print("worst single launches:")
 for l, st, name, ms, tf, mult in sorted(rows, reverse=True)[:25]:
     print(f"  lost {l:6.2f} ms  {ms*1e3:8.1f} us x{mult}  {tf:6.1f} TF/s  {st}:{name}")
