@@ -29,6 +29,14 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// The dispatcher places workgroup `id` of a launch on XCD id % 8 (eight XCDs, a private L2 each).  Returns the position of
+// workgroup `id` in an order in which every XCD owns ONE contiguous run of the `nwg` work items: neighbours in the work raster
+// (tiles sharing halos, the N tiles of one row of A) then share an L2.  A bijection on [0, nwg): pure speed, any order is correct.
+__device__ inline int xcd_contiguous(int id, int nwg) {
+  const int xcd = id & 7, local = id >> 3, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 }  // namespace premvos
 
 #define PV_REQUIRE(cond, ...) \

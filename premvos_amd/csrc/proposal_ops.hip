@@ -332,27 +332,45 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
       const float hs = (by2 - by1) * (float)(H - 1) / (float)(crop - 1);
       const float ws = (bx2 - bx1) * (float)(W - 1) / (float)(crop - 1);
       const float* fb = fm + (long)img * H * W * ps + cg * 4;
+      // the 2x2 samples of the bin: coordinates first, then all 16 corner loads (samples outside the map are not loaded:
+      // extrapolation value 0), then the bilinear sums in sample order -- no load waits for arithmetic on an earlier one
+      bool oky[2], okx[2];
+      int yt[2], yb[2], xl[2], xr[2];
+      float yl[2], xlp[2];
+#pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float in_y = by1 * (float)(H - 1) + (float)(2 * by_ + j) * hs;
-        if (in_y < 0.f || in_y > (float)(H - 1)) continue;
-        const int yt = (int)floorf(in_y), yb = (int)ceilf(in_y);
-        const float yl = in_y - floorf(in_y);
-        for (int i = 0; i < 2; ++i) {
-          const float in_x = bx1 * (float)(W - 1) + (float)(2 * bx_ + i) * ws;
-          if (in_x < 0.f || in_x > (float)(W - 1)) continue;
-          const int xl = (int)floorf(in_x), xr = (int)ceilf(in_x);
-          const float xlp = in_x - floorf(in_x);
-          const float4 tl = *reinterpret_cast<const float4*>(fb + ((long)yt * W + xl) * ps);
-          const float4 tr = *reinterpret_cast<const float4*>(fb + ((long)yt * W + xr) * ps);
-          const float4 bl = *reinterpret_cast<const float4*>(fb + ((long)yb * W + xl) * ps);
-          const float4 br = *reinterpret_cast<const float4*>(fb + ((long)yb * W + xr) * ps);
-          float top, bot;
-          top = tl.x + (tr.x - tl.x) * xlp; bot = bl.x + (br.x - bl.x) * xlp; acc.x += top + (bot - top) * yl;
-          top = tl.y + (tr.y - tl.y) * xlp; bot = bl.y + (br.y - bl.y) * xlp; acc.y += top + (bot - top) * yl;
-          top = tl.z + (tr.z - tl.z) * xlp; bot = bl.z + (br.z - bl.z) * xlp; acc.z += top + (bot - top) * yl;
-          top = tl.w + (tr.w - tl.w) * xlp; bot = bl.w + (br.w - bl.w) * xlp; acc.w += top + (bot - top) * yl;
-        }
+        oky[j] = !(in_y < 0.f || in_y > (float)(H - 1));
+        yt[j] = (int)floorf(in_y), yb[j] = (int)ceilf(in_y);
+        yl[j] = in_y - floorf(in_y);
+        const float in_x = bx1 * (float)(W - 1) + (float)(2 * bx_ + j) * ws;
+        okx[j] = !(in_x < 0.f || in_x > (float)(W - 1));
+        xl[j] = (int)floorf(in_x), xr[j] = (int)ceilf(in_x);
+        xlp[j] = in_x - floorf(in_x);
       }
+      float4 tl[2][2], tr[2][2], bl[2][2], br[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (oky[j] && okx[i]) {
+            tl[j][i] = *reinterpret_cast<const float4*>(fb + ((long)yt[j] * W + xl[i]) * ps);
+            tr[j][i] = *reinterpret_cast<const float4*>(fb + ((long)yt[j] * W + xr[i]) * ps);
+            bl[j][i] = *reinterpret_cast<const float4*>(fb + ((long)yb[j] * W + xl[i]) * ps);
+            br[j][i] = *reinterpret_cast<const float4*>(fb + ((long)yb[j] * W + xr[i]) * ps);
+          }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (oky[j] && okx[i]) {
+            const float4 a = tl[j][i], b = tr[j][i], c = bl[j][i], d = br[j][i];
+            float top, bot;
+            top = a.x + (b.x - a.x) * xlp[i]; bot = c.x + (d.x - c.x) * xlp[i]; acc.x += top + (bot - top) * yl[j];
+            top = a.y + (b.y - a.y) * xlp[i]; bot = c.y + (d.y - c.y) * xlp[i]; acc.y += top + (bot - top) * yl[j];
+            top = a.z + (b.z - a.z) * xlp[i]; bot = c.z + (d.z - c.z) * xlp[i]; acc.z += top + (bot - top) * yl[j];
+            top = a.w + (b.w - a.w) * xlp[i]; bot = c.w + (d.w - c.w) * xlp[i]; acc.w += top + (bot - top) * yl[j];
+          }
       acc.x *= 0.25f; acc.y *= 0.25f; acc.z *= 0.25f; acc.w *= 0.25f;
     }
     *reinterpret_cast<float4*>(out + ((r * outsz + by_) * outsz + bx_) * out_ps + cg * 4) = acc;

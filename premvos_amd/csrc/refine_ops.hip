@@ -150,22 +150,28 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restr
     if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + cg * 4);
 #pragma unroll
     for (int o = 0; o < TW; ++o) acc[o] = bv;
-    const int ix0 = ox0 * STRIDE - pl;
+    const int ix0 = ox0 * STRIDE - pl, iy0 = oy * STRIDE - pt;
+    // all 3 x NCOL taps are requested before the first one is used; taps outside the map are not loaded (lanes masked off)
+    // and zeroed at use -- a select right behind a load would make the wave wait for it before issuing the next load
+    float4 raw[3][NCOL];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int iy = oy * STRIDE - pt + j;
-      if ((unsigned)iy >= (unsigned)h) continue;
-      const float* rowp = in + (((long)b * h + iy) * w) * in_ps + cg * 4;
+      const float* rowp = in + (((long)b * h + iy0 + j) * w) * in_ps + cg * 4;
+#pragma unroll
+      for (int cx = 0; cx < NCOL; ++cx)
+        if ((unsigned)(iy0 + j) < (unsigned)h && (unsigned)(ix0 + cx) < (unsigned)w)
+          raw[j][cx] = *reinterpret_cast<const float4*>(rowp + (long)(ix0 + cx) * in_ps);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if ((unsigned)(iy0 + j) >= (unsigned)h) continue;
       float4 v[NCOL];
 #pragma unroll
       for (int cx = 0; cx < NCOL; ++cx) {
-        const int ix = ix0 + cx;
-        v[cx] = ((unsigned)ix < (unsigned)w) ? *reinterpret_cast<const float4*>(rowp + (long)ix * in_ps)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRE_RELU) {
-          v[cx].x = fmaxf(v[cx].x, 0.f); v[cx].y = fmaxf(v[cx].y, 0.f);
-          v[cx].z = fmaxf(v[cx].z, 0.f); v[cx].w = fmaxf(v[cx].w, 0.f);
-        }
+        const bool ok = (unsigned)(ix0 + cx) < (unsigned)w;
+        const float lo = PRE_RELU ? 0.f : -INFINITY;
+        const float4 t = raw[j][cx];
+        v[cx] = make_float4(ok ? fmaxf(t.x, lo) : 0.f, ok ? fmaxf(t.y, lo) : 0.f, ok ? fmaxf(t.z, lo) : 0.f, ok ? fmaxf(t.w, lo) : 0.f);
       }
 #pragma unroll
       for (int o = 0; o < TW; ++o)
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restr
 // as soon as its third input row has been consumed (so only ~3 accumulator rows are live).  Per output this is
 // NROW*NCOL/(TR*TW) float4 loads (1.9 at 8x4, 1.96 at 5x5) against 4.5 for the row kernel; accumulation order per
 // output (bias, then taps in (ky,kx) order) is the same as in the other two kernels -> identical bits.
-template <bool PRE_RELU, int STRIDE, int TW, int TR>
+template <bool PRE_RELU, int STRIDE, int TW, int TR, bool AHEAD>
 __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __restrict__ in, int in_ps, int n, int h, int w,
                                                              int c4, const float* __restrict__ wgt,
                                                              const float* __restrict__ bias, float* __restrict__ out,
@@ -205,7 +211,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
   constexpr int NROW = (TR - 1) * STRIDE + 3;
   const int xt = dil * (((wo + dil - 1) / dil + TW - 1) / TW), yt = dil * (((ho + dil - 1) / dil + TR - 1) / TR);
   const long total = (long)n * yt * xt * c4;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+  // Workgroup b runs on XCD b % 8 (private L2 each): give every XCD a contiguous run of the (image, tile row, tile column,
+  // channel group) raster, so that the tiles which share halo rows / columns fetch them through ONE L2.
+  // (measured: +8 % on the 25x25 maps with 5x5 tiles, a loss on the large entry-flow maps, where the plain order keeps the
+  // eight XCDs on neighbouring DRAM pages)
+  const long vblock = TW == 5 ? premvos::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  for (long idx = vblock * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int cg = idx % c4;
     long t = idx / c4;
     const int tx = t % xt;
@@ -224,21 +235,30 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
       for (int q = 0; q < TW; ++q) acc[o][q] = bv;
     const int ix0 = ox0 * STRIDE - pl, iy0 = oy0 * STRIDE - pt;
     const float* imgp = in + ((long)b * h * w) * in_ps + cg * 4;
+    // Rows are loaded one ahead of the row being consumed (two rows of 16-byte loads per lane in flight).  Out-of-image taps
+    // are not loaded (their lanes are masked off) and are zeroed when the row is consumed: a select right after the load would
+    // make the wave wait for it before issuing the next one.
+    auto row_ok = [&](int j) { return (unsigned)(iy0 + j * dil) < (unsigned)h; };
+    auto col_ok = [&](int cx) { return (unsigned)(ix0 + cx * dil) < (unsigned)w; };
+    auto load_row = [&](int j, float4* v) {
+      const float* rowp = imgp + ((long)(iy0 + j * dil) * w) * in_ps;
+#pragma unroll
+      for (int cx = 0; cx < NCOL; ++cx)
+        if (row_ok(j) && col_ok(cx)) v[cx] = *reinterpret_cast<const float4*>(rowp + (long)(ix0 + cx * dil) * in_ps);   // else: never read
+    };
+    float4 vbuf[2][NCOL];
+    load_row(0, vbuf[0]);
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
-      const int iy = iy0 + j * dil;
-      const bool rowok = (unsigned)iy < (unsigned)h;
-      const float* rowp = imgp + ((long)iy * w) * in_ps;
+      if (AHEAD && j + 1 < NROW) load_row(j + 1, vbuf[(j + 1) & 1]);
+      if (!AHEAD && j > 0) load_row(j, vbuf[j & 1]);
       float4 v[NCOL];
 #pragma unroll
       for (int cx = 0; cx < NCOL; ++cx) {
-        const int ix = ix0 + cx * dil;
-        v[cx] = (rowok && (unsigned)ix < (unsigned)w) ? *reinterpret_cast<const float4*>(rowp + (long)ix * in_ps)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRE_RELU) {
-          v[cx].x = fmaxf(v[cx].x, 0.f); v[cx].y = fmaxf(v[cx].y, 0.f);
-          v[cx].z = fmaxf(v[cx].z, 0.f); v[cx].w = fmaxf(v[cx].w, 0.f);
-        }
+        const bool ok = row_ok(j) && col_ok(cx);
+        const float4 t = vbuf[j & 1][cx];
+        const float lo = PRE_RELU ? 0.f : -INFINITY;          // max(x, -inf) == x: one instruction either way
+        v[cx] = make_float4(ok ? fmaxf(t.x, lo) : 0.f, ok ? fmaxf(t.y, lo) : 0.f, ok ? fmaxf(t.z, lo) : 0.f, ok ? fmaxf(t.w, lo) : 0.f);
       }
 #pragma unroll
       for (int o = 0; o < TR; ++o) {
@@ -450,8 +470,14 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
                      (dilation * (((wo + dilation - 1) / dilation + tw - 1) / tw)) * c4;
     const dim3 g(grid_for(tot)), b(256);
 #define PV_DW_TILE(PR, ST, TW_, TR_)                                                                                  \
-  hipLaunchKernelGGL((dwconv3x3_tile_kernel<PR, ST, TW_, TR_>), g, b, 0, s, in, in_ps, n, h, w, c4, wgt, bias, out,   \
-                     out_ps, ho, wo, pt, pl, act, c_pad, dilation)
+  do {                                                                                                                \
+    if (dilation <= 4)                                                                                                \
+      hipLaunchKernelGGL((dwconv3x3_tile_kernel<PR, ST, TW_, TR_, true>), g, b, 0, s, in, in_ps, n, h, w, c4, wgt, bias, \
+                         out, out_ps, ho, wo, pt, pl, act, c_pad, dilation);                                          \
+    else /* wide atrous: most taps of the short sub-lattices fall outside the map; a second row in flight only costs registers */ \
+      hipLaunchKernelGGL((dwconv3x3_tile_kernel<PR, ST, TW_, TR_, false>), g, b, 0, s, in, in_ps, n, h, w, c4, wgt, bias, \
+                         out, out_ps, ho, wo, pt, pl, act, c_pad, dilation);                                          \
+  } while (0)
 #define PV_DW_SHAPE(PR, ST)                                                                                           \
   do {                                                                                                                \
     if (tr == 5) PV_DW_TILE(PR, ST, 5, 5);                                                                            \
