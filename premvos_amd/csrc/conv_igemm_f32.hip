@@ -190,6 +190,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
       for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
 #pragma unroll
       for (int ni = 0; ni < NTL; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+      // four k-steps in a row on ONE accumulator (dependent MFMAs issue back to back at the pipe's own 64-cycle pace; measured:
+      // walking the accumulators round-robin instead is 1.5 % slower)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
