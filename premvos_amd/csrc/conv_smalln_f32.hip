@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const premvos_conv_des
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int cu = c + u * LPP * 4;
-            v[u] = cu < p.cin_pad ? *reinterpret_cast<const float4*>(src + cu) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cu < p.cin_pad) v[u] = *reinterpret_cast<const float4*>(src + cu);   // (never read otherwise; no select behind the load)
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
