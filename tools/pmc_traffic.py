@@ -9,7 +9,8 @@ import csv
 import json
 import sys
 
-KERNELS = ("conv_igemm_f32_kernel", "wino_gemm_kernel", "wino_output_kernel", "splitk_reduce_kernel", "conv_smalln_kernel")
+KERNELS = ("conv_igemm_f32_kernel", "wino_gemm_kernel", "wino_output_kernel", "wino_fused_kernel", "splitk_reduce_kernel",
+           "conv_smalln_kernel")
 
 
 def total(path, counter):
