@@ -117,3 +117,25 @@ def test_load_any_errors_are_explicit(tmp_path):
     torch.save([1, 2], tmp_path / "list.pt")
     with pytest.raises(ValueError, match="pickled dict"):
         W.load_any(str(tmp_path / "list.pt"), "refinement")
+
+
+def test_importers_ignore_optimizer_slots_and_bookkeeping_variables():
+    """Real TF checkpoints carry more than the inference variables (global_step, learning_rate, Momentum / Adam slots named
+    <variable>/<slot>): the name maps take what the nets need and drop the rest."""
+    import numpy as np
+    from premvos_amd import synth
+    from premvos_amd import weights as W
+    w = synth.proposal_weights(0, (1, 1, 1, 1))
+    tfv = W.proposal_weights_to_tf(w)
+    want = sorted(W.proposal_weights_from_tf(tfv))
+    tfv.update({"global_step": np.array(5, np.int64), "learning_rate": np.array(0.003, np.float32),
+                "conv0/W/Momentum": np.zeros_like(tfv["conv0/W"]), "group0/block0/conv1/bn/gamma/Momentum": np.zeros(64, np.float32)})
+    assert sorted(W.proposal_weights_from_tf(tfv)) == want
+    rw = synth.refinement_weights(0, 1)
+    tv = W.refinement_weights_to_tf(rw)
+    want = sorted(W.refinement_weights_from_tf(tv))
+    tv.update({"global_step": np.array(5, np.int64),
+               "xception_65/entry_flow/conv1_1/weights/Adam": np.zeros((3, 3, 4, 32), np.float32),
+               "xception_65/entry_flow/conv1_1/weights/Adam_1": np.zeros((3, 3, 4, 32), np.float32),
+               "xception_65/entry_flow/conv1_1/BatchNorm/beta/Adam": np.zeros((32,), np.float32), "beta1_power": np.array(0.9, np.float32)})
+    assert sorted(W.refinement_weights_from_tf(tv)) == want
