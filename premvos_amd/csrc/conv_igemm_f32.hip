@@ -505,6 +505,7 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   pick_tile(d, &bm, &bn);
   if (pick_kb(d) == 32) {
     switch ((bm << 16) | bn) {
+      case (256 << 16) | 128: return launch_cfg<256, 128, 4, 2, 32>(d, s);
       case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2, 32>(d, s);
       case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2, 32>(d, s);
       case (64 << 16) | 128: return launch_cfg<64, 128, 2, 2, 32>(d, s);
@@ -512,6 +513,7 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
     }
   }
   switch ((bm << 16) | bn) {
+    case (256 << 16) | 128: return launch_cfg<256, 128, 4, 2>(d, s);      // 8 waves of 64x64: half the B staging per MFMA
     case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2>(d, s);
     case (128 << 16) | 96: return launch_cfg<128, 96, 4, 1>(d, s);
     case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2>(d, s);
@@ -532,6 +534,7 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   int bm, bn;
   pick_tile(*dp, &bm, &bn);
   switch ((bm << 16) | bn) {
+    case (256 << 16) | 128: return ws_cfg<256, 128, 4, 2>(*dp);
     case (128 << 16) | 128: return ws_cfg<128, 128, 2, 2>(*dp);
     case (128 << 16) | 96: return ws_cfg<128, 96, 4, 1>(*dp);
     case (128 << 16) | 64: return ws_cfg<128, 64, 2, 2>(*dp);

@@ -255,6 +255,8 @@ def _candidates(d: ConvDesc):
         tiles = [(128, 64), (64, 64)]
     else:
         tiles = [(128, 128), (64, 128), (128, 64), (64, 64)]
+        if d.precision == _lib.PREC_F32 and m >= 256 * 512 and os.environ.get("PREMVOS_TILE256", "1") != "0":
+            tiles.append((256, 128))           # 8 waves of 64x64 at <= 128 VGPRs: four waves per SIMD, half the B staging per MFMA
         if d.precision == _lib.PREC_F32 and 64 < d.cout <= 96:
             tiles.append((128, 96))
     out = []
@@ -271,7 +273,7 @@ def _candidates(d: ConvDesc):
             out.extend((3, v, -1, 0, 0) for v in (() if d.cout <= 32 else (3, 5) if d.cout <= 64 else (0, 2, 4, 6)))
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
-        stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((128, 128), (128, 64), (64, 128))) else [16]
+        stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((256, 128), (128, 128), (128, 64), (64, 128))) else [16]
         splits = [-1] + ([2, 4] if (nt < 512 and d.k_pad >= 512) else []) + ([8] if (nt < 128 and d.k_pad >= 2048) else [])
         for st in stages:
             for sk in splits:

@@ -70,7 +70,7 @@ def test_conv2d_matches_torch(case):
     assert out.buf[..., :5].abs().max().item() == 0 and out.buf[..., 5 + cout:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("hint", [(128, 128), (128, 96), (128, 64), (128, 32), (64, 128), (64, 64), (64, 32)])
+@pytest.mark.parametrize("hint", [(256, 128), (128, 128), (128, 96), (128, 64), (128, 32), (64, 128), (64, 64), (64, 32)])
 def test_conv2d_every_tile_config(hint):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
