@@ -223,6 +223,63 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
     }
     return;
   }
+  // ---- epilogue, wide form: the accumulators of one wave row go through LDS (free after the main loop) so that every lane
+  // stores 16 bytes of a pixel's contiguous channel run (an MFMA accumulator holds ONE column per lane: straight from
+  // registers that is a 4-byte store per element, 64 store instructions per lane for a 128x128 tile -- short-K layers with
+  // many output channels were store-ISSUE-bound at ~1.7 TB/s).  Bias, residual (16-byte loads) and activation at read-back.
+  if constexpr (!PIXSHUF) {
+    const bool wide = (p.cout & 3) == 0 && (p.out_ps & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15u) == 0 &&
+                      (p.res == nullptr || ((p.res_ps & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15u) == 0)) &&
+                      (p.bias == nullptr || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0);
+    constexpr int EP = BN + 4;                                   // row pitch of the staged block (floats)
+    static_assert(WTM * EP <= 2 * BUF, "the staged wave row must fit the operand buffers");
+    if (wide) {                                                  // kernel-uniform
+      float* stg = lds_dyn;
+#pragma unroll 1
+      for (int wr = 0; wr < WM; ++wr) {
+        if (wave / WN == wr) {
+#pragma unroll
+          for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                stg[row * EP + wn0 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+              }
+        }
+        __syncthreads();
+        constexpr int C4 = BN / 4, UNITS = WTM * C4;
+#pragma unroll
+        for (int u = tid; u < UNITS; u += NT) {
+          const int row = u / C4, c4 = u - row * C4;
+          const int m = m0 + wr * WTM + row, col = n0 + c4 * 4;
+          if (m < M && col < p.cout) {
+            float4 v = *reinterpret_cast<const float4*>(&stg[row * EP + c4 * 4]);
+            if (p.bias != nullptr) {
+              const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
+              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (p.res != nullptr) {
+              const float4 rv = *reinterpret_cast<const float4*>(p.res + (long)m * p.res_ps + col);
+              v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            if (p.act == PREMVOS_ACT_RELU) {
+              v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            } else if (p.act == PREMVOS_ACT_LEAKY) {
+              v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+              v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+            } else if (p.act == PREMVOS_ACT_SIGMOID) {
+              v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+            }
+            *reinterpret_cast<float4*>(p.out + (long)m * p.out_ps + col) = v;
+          }
+        }
+        if (wr + 1 < WM) __syncthreads();
+      }
+      return;
+    }
+  }
   // ---- epilogue: bias + residual + activation, 128-byte channel runs per pixel -------------
 #pragma unroll
   for (int ni = 0; ni < NTL; ++ni) {
@@ -372,6 +429,7 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   const bool pw = d.kh == 1 && d.kw == 1 && d.pt == 0 && d.pl == 0;
   int splits = pick_splits(d, BM, BN, KB);
   const int KT = premvos::cdiv(d.k_pad, KB);
+  const int lds_bytes = LDS_BYTES;
   if (splits > 1) {
     const int kt_per = premvos::cdiv(KT, splits);
     splits = premvos::cdiv(KT, kt_per);
@@ -380,9 +438,9 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
     if (splits > 1 && d.workspace != nullptr && (long)d.workspace_bytes >= need) {
       grid.z = splits;
       if (pw)
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB, true>), grid, block, LDS_BYTES, s, d, kt_per, 0);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB, true>), grid, block, lds_bytes, s, d, kt_per, 0);
       else
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), grid, block, LDS_BYTES, s, d, kt_per, 0);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), grid, block, lds_bytes, s, d, kt_per, 0);
       int rc = premvos::check_launch("conv_igemm_f32(split-k)");
       if (rc) return rc;
       return premvos::launch_splitk_reduce(d, splits, ncols, s, 0);
@@ -406,20 +464,20 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   }
   const dim3 gmain(grid.x - tail, grid.y);
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>), gmain, block, LDS_BYTES, s, d, 0, 0);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>), gmain, block, lds_bytes, s, d, 0, 0);
   else if (pw)
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB, true>), gmain, block, LDS_BYTES, s, d, 0, 0);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB, true>), gmain, block, lds_bytes, s, d, 0, 0);
   else
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>), gmain, block, LDS_BYTES, s, d, 0, 0);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>), gmain, block, lds_bytes, s, d, 0, 0);
   int rc = premvos::check_launch("conv_igemm_f32");
   if (rc || !tail) return rc;
   const int mt0 = (int)grid.x - tail;
   if (pw)
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB, true>), dim3(tail, grid.y, tsplits), block,
-                       LDS_BYTES, s, d, tkt_per, mt0);
+                       lds_bytes, s, d, tkt_per, mt0);
   else
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>), dim3(tail, grid.y, tsplits), block,
-                       LDS_BYTES, s, d, tkt_per, mt0);
+                       lds_bytes, s, d, tkt_per, mt0);
   rc = premvos::check_launch("conv_igemm_f32(tail split-k)");
   if (rc) return rc;
   return premvos::launch_splitk_reduce(d, tsplits, grid.y * BN, s, mt0 * BM);
