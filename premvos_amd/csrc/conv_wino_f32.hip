@@ -394,7 +394,68 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
     __syncthreads();
   }
 
-  // bias + residual + activation, the 2x2 pixels of every tile row this lane holds
+  // Wide epilogue (as in conv_igemm_f32.hip): one output position (ya, yb) of one wave row at a time goes through the idle operand
+  // LDS, then every lane handles 16 bytes of a pixel's channel run: bias, residual (16-byte load), activation, 16-byte store.
+  {
+    const bool wide = (p.out_ps & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15u) == 0 &&
+                      (p.res == nullptr || ((p.res_ps & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15u) == 0)) &&
+                      (p.bias == nullptr || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0);       // (cout % 4 == 0 is a precondition)
+    constexpr int EP = BN + 4;
+    static_assert(WTM * EP <= 2 * BUF, "the staged wave row must fit the operand buffers");
+    if (wide) {                                                  // kernel-uniform
+      float* stg = lds_dyn;
+#pragma unroll 1
+      for (int wr = 0; wr < WM; ++wr)
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+          for (int yb = 0; yb < 2; ++yb) {
+            __syncthreads();                                       // the previous block has been read (first: the K loop is over)
+            if (wave / WN == wr) {
+#pragma unroll
+              for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r)
+                    stg[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP + wn0 + ni * 32 + (lane & 31)] = Y[ya][yb][mi][ni][r];
+            }
+            __syncthreads();
+            constexpr int C4 = BN / 4, UNITS = WTM * C4;
+#pragma unroll
+            for (int u = tid; u < UNITS; u += NT) {
+              const int row = u / C4, c4 = u - row * C4;
+              const int m = m0 + wr * WTM + row, col = n0 + c4 * 4;
+              if (m >= Mt || col >= p.cout) continue;
+              const int n = m / tpi, rem = m - n * tpi;
+              const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+              const int oy = 2 * ty + ya, ox = 2 * tx + yb;
+              if (oy >= p.ho || ox >= p.wo) continue;
+              const long pix = ((long)n * p.ho + oy) * p.wo + ox;
+              float4 v = *reinterpret_cast<const float4*>(&stg[row * EP + c4 * 4]);
+              if (p.bias != nullptr) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + col);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+              }
+              if (p.res != nullptr) {
+                const float4 rv = *reinterpret_cast<const float4*>(p.res + pix * p.res_ps + col);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+              }
+              if (p.act == PREMVOS_ACT_RELU) {
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+              } else if (p.act == PREMVOS_ACT_LEAKY) {
+                v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+                v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+              } else if (p.act == PREMVOS_ACT_SIGMOID) {
+                v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+              }
+              *reinterpret_cast<float4*>(p.out + pix * p.out_ps + col) = v;
+            }
+          }
+      return;
+    }
+  }
+  // scalar form (unaligned channel windows): bias + residual + activation, the 2x2 pixels of every tile row this lane holds
   float bv[NTL];
   int cols[NTL];
 #pragma unroll
