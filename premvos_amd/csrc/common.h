@@ -29,6 +29,17 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Four registers with an arbitrary (but, for the compiler, defined) content and no instruction behind them: the destination of a
+// load that only the in-range lanes execute.  `t = zero; if (ok) t = load;` would be the obvious spelling, but hipcc turns it into
+// load + select, and a select behind a load makes the wave wait for that load before it issues the next one (measured on the
+// depthwise kernels: 3.5 instead of 4.6-5.8 TB/s); out-of-range lanes are masked when the value is USED instead.  (Where even this
+// costs -- the row-ahead depthwise tile kernel -- the register is left unwritten and provably never read for those lanes.)
+__device__ inline float4 arbitrary4() {
+  float4 t;
+  asm("" : "=v"(t.x), "=v"(t.y), "=v"(t.z), "=v"(t.w));     // (not volatile: free to move, nothing to order)
+  return t;
+}
+
 // The dispatcher places workgroup `id` of a launch on XCD id % 8 (eight XCDs, a private L2 each).  Returns the position of
 // workgroup `id` in an order in which every XCD owns ONE contiguous run of the `nwg` work items: neighbours in the work raster
 // (tiles sharing halos, the N tiles of one row of A) then share an L2.  A bijection on [0, nwg): pure speed, any order is correct.

@@ -158,9 +158,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restr
     for (int j = 0; j < 3; ++j) {
       const float* rowp = in + (((long)b * h + iy0 + j) * w) * in_ps + cg * 4;
 #pragma unroll
-      for (int cx = 0; cx < NCOL; ++cx)
+      for (int cx = 0; cx < NCOL; ++cx) {
+        raw[j][cx] = premvos::arbitrary4();
         if ((unsigned)(iy0 + j) < (unsigned)h && (unsigned)(ix0 + cx) < (unsigned)w)
           raw[j][cx] = *reinterpret_cast<const float4*>(rowp + (long)(ix0 + cx) * in_ps);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -243,8 +245,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
     auto load_row = [&](int j, float4* v) {
       const float* rowp = imgp + ((long)(iy0 + j * dil) * w) * in_ps;
 #pragma unroll
-      for (int cx = 0; cx < NCOL; ++cx)
-        if (row_ok(j) && col_ok(cx)) v[cx] = *reinterpret_cast<const float4*>(rowp + (long)(ix0 + cx * dil) * in_ps);   // else: never read
+      for (int cx = 0; cx < NCOL; ++cx) {
+        // (measured: giving the masked-off lanes a defined arbitrary content helps the variant without a row in flight --
+        //  wide atrous layers 461 -> 380 us -- and costs the one with it 126 -> 207 us; there an out-of-range tap's register is
+        //  simply never read, see the conditional at the use)
+        if constexpr (!AHEAD) v[cx] = premvos::arbitrary4();
+        if (row_ok(j) && col_ok(cx)) v[cx] = *reinterpret_cast<const float4*>(rowp + (long)(ix0 + cx * dil) * in_ps);
+      }
     };
     float4 vbuf[2][NCOL];
     load_row(0, vbuf[0]);
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
 #pragma unroll
       for (int cx = 0; cx < NCOL; ++cx) {
         const bool ok = row_ok(j) && col_ok(cx);
-        const float4 t = vbuf[j & 1][cx];
+        const float4& t = vbuf[j & 1][cx];                    // (read only where ok: the conditional below)
         const float lo = PRE_RELU ? 0.f : -INFINITY;          // max(x, -inf) == x: one instruction either way
         v[cx] = make_float4(ok ? fmaxf(t.x, lo) : 0.f, ok ? fmaxf(t.y, lo) : 0.f, ok ? fmaxf(t.z, lo) : 0.f, ok ? fmaxf(t.w, lo) : 0.f);
       }
