@@ -170,7 +170,9 @@ def context_boxes(boxes_xywh: np.ndarray, height: int, width: int, feed: bool = 
 def make_crop(frame_rgb_u8: np.ndarray, box_xywh_int: Sequence[int], feed: bool = True) -> np.ndarray:
     """-> normalised float32 [128,128,3] (DAVIS_Forward_Feed.py:62-84 / Similarity.py:288-297)."""
     x, y, w, h = (int(v) for v in box_xywh_int)
-    img = frame_rgb_u8.astype(np.float32) / np.float32(255)
+    # in-merge feed: `self.image / 255` (DAVIS_Forward_Feed.py:27); batch stage: tf.image.convert_image_dtype(uint8 -> float32) of
+    # load_image_tensorflow (Util/Reader.py:162) = cast * float32(1 / 255) -- the two differ in the last bit for 39 % of the values
+    img = frame_rgb_u8.astype(np.float32) / np.float32(255) if feed else frame_rgb_u8.astype(np.float32) * np.float32(1.0 / 255.0)
     if feed and min(h, w) <= 10:
         out = np.zeros((INPUT_SIZE, INPUT_SIZE, 3), np.float32)
     else:

@@ -44,8 +44,13 @@ __global__ __launch_bounds__(256) void reid_input_kernel(const uint8_t* __restri
       const uint8_t* f11 = frame + ((long)(by + yhi) * W + bx + xhi) * 3;
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        const float tl = (float)f00[ch] / 255.f, tr = (float)f01[ch] / 255.f;
-        const float bl = (float)f10[ch] / 255.f, br = (float)f11[ch] / 255.f;
+        // in-merge feed: image / 255 (DAVIS_Forward_Feed.py:27); batch stage: tf.image.convert_image_dtype = cast * (1 / 255)
+        // (Util/Reader.py:162) -- not the same float for 39 % of the byte values
+        const float r255 = 1.0f / 255.0f;
+        const float tl = zero_small ? (float)f00[ch] / 255.f : (float)f00[ch] * r255;
+        const float tr = zero_small ? (float)f01[ch] / 255.f : (float)f01[ch] * r255;
+        const float bl = zero_small ? (float)f10[ch] / 255.f : (float)f10[ch] * r255;
+        const float br = zero_small ? (float)f11[ch] / 255.f : (float)f11[ch] * r255;
         const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
         v[ch] = top + (bot - top) * ty;
       }

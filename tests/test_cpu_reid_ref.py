@@ -76,3 +76,21 @@ def test_crop_pipeline_oracle_and_product_vs_reference_feed_dataset():
     assert np.abs(crops.mean(axis=(1, 2), dtype=np.float64) - REF["crops_mean"]).max() < 1e-5
     small = [i for i, b in enumerate(ctx) if min(b[2], b[3]) <= 10]
     assert small, "the fixture holds a box under the 10-pixel rule"
+
+
+def test_batch_stage_crops_oracle_vs_reference_similarity_dataset():
+    """SimilarityDataset._load_crop_helper (Similarity.py:264-298, the DAVIS_Forward_Similarity stage) executed on the stand-in:
+    excess >= 0, no small-box rule, and the image scaled as convert_image_dtype does (uint8 * float32(1/255), not / 255)."""
+    frame, boxes = REF["sim_frame"], REF["sim_boxes_xywh"]
+    h, w = frame.shape[:2]
+    ctx = R.context_boxes(boxes, h, w, feed=False)
+    assert [[int(b[3]), int(b[2])] for b in ctx] == REF["sim_crop_hw"].tolist()          # the [y:y+h, x:x+w] slices
+    from premvos_amd.reid import context_boxes
+    assert np.array_equal(context_boxes(boxes, h, w, False), ctx)
+    crops = np.stack([R.make_crop(frame, b, feed=False) for b in ctx])
+    assert np.array_equal(crops[:, ::3, ::3], REF["sim_crops_sub"])                        # bit for bit
+    assert np.abs(crops.mean(axis=(1, 2), dtype=np.float64) - REF["sim_crops_mean"]).max() < 1e-6
+    # the in-merge scaling (/ 255) is NOT the same float everywhere
+    other = np.stack([R.make_crop(frame, b, feed=True) for b in ctx if min(b[2], b[3]) > 10])
+    same = np.stack([c for c, b in zip(crops, ctx) if min(b[2], b[3]) > 10])
+    assert not np.array_equal(other, same)

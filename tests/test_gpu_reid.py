@@ -155,3 +155,14 @@ def test_full_depth_net_and_crops_vs_reference_executed_fixture():
     got = out.cpu().numpy()[..., :3]
     assert np.abs(got[:, ::3, ::3] - ref["crops_sub"]).max() < 3e-6
     assert np.abs(got.mean(axis=(1, 2), dtype=np.float64) - ref["crops_mean"]).max() < 1e-5
+    # batch stage: SimilarityDataset._load_crop_helper (excess >= 0, convert_image_dtype scaling)
+    frame, boxes = ref["sim_frame"], ref["sim_boxes_xywh"]
+    h, w = frame.shape[:2]
+    cb = context_boxes(boxes, h, w, False)
+    out = torch.zeros((len(cb), 128, 128, 4), device="cuda")
+    dimg, dcb = torch.from_numpy(frame).cuda(), torch.from_numpy(cb).cuda()
+    _lib.check(_lib.load().premvos_reid_input_u8(dimg.data_ptr(), h, w, dcb.data_ptr(), len(cb), 128, 0, out.data_ptr(),
+                                                 _lib.current_stream()), "reid_input")
+    got = out.cpu().numpy()[..., :3]
+    assert np.abs(got[:, ::3, ::3] - ref["sim_crops_sub"]).max() < 3e-6
+    assert np.abs(got.mean(axis=(1, 2), dtype=np.float64) - ref["sim_crops_mean"]).max() < 1e-5

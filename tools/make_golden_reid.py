@@ -40,6 +40,7 @@ from tfshim import T, _np  # noqa: E402
 tf = slimshim.install()
 slimshim.install_output_layer_api(tf)
 tfshim.STUB_ROOTS += ("skimage", "partialflow")
+os.environ.setdefault("USER", "nobody")       # datasets/Util/Util.py:55 builds a default data path from it
 CODE = os.path.join(REF, "code")
 pkg = types.ModuleType("ReID_net")
 pkg.__path__ = [os.path.join(CODE, "ReID_net")]
@@ -167,12 +168,37 @@ def run_crops(cfg):
             "crops_mean": np.asarray(imgs.a).mean(axis=(1, 2), dtype=np.float64).astype(np.float32)}
 
 
+def run_similarity_crops(cfg):
+    """SimilarityDataset._load_crop_helper (datasets/Similarity/Similarity.py:264-298), the crop of the BATCH stage
+    (DAVIS_Forward_Similarity): image via load_image_tensorflow = decode + tf.image.convert_image_dtype(float32), i.e. uint8 *
+    float32(1/255) -- NOT the /255 of the in-merge feed --, context region, tf.round, excess >= 0, slice, resize_images, normalize.
+    The decoder is replaced by the frame itself; convert_image_dtype is restated (cast, then multiply by 1/max)."""
+    from ReID_net.datasets.Similarity import Similarity as SM
+    rng = np.random.default_rng(13)
+    h, w = 90, 140
+    frame = (rng.random((h, w, 3)) * 255).astype(np.uint8)
+    boxes = np.array([[10.2, 12.7, 60.5, 40.1], [95.0, 50.0, 70.0, 60.0], [-4.0, -3.0, 30.0, 25.5], [40.0, 30.0, 9.0, 30.0],
+                      [0.0, 0.0, 140.0, 90.0], [20.5, 10.5, 33.5, 47.5]], np.float32)
+    SM.load_image_tensorflow = lambda fn, jpg, channels=None: T(frame.astype(np.float32) * np.float32(1.0 / 255.0))
+    me = types.SimpleNamespace(jpg=True, context_region_factor=cfg.float("context_region_factor_val", 1.2),
+                               input_size=tuple(cfg.int_list("input_size")), augmentors=[])
+    crops, raw_shapes = [], []
+    for b in boxes:
+        norm, img, cropped = SM.SimilarityDataset._load_crop_helper(me, "frame.jpg", T(b.copy()))
+        crops.append(np.asarray(norm.a))
+        raw_shapes.append(list(np.asarray(cropped.a).shape[:2]))
+    crops = np.stack(crops)
+    return {"sim_frame": frame, "sim_boxes_xywh": boxes, "sim_crop_hw": np.array(raw_shapes, np.int32), "sim_crops_sub": crops[:, ::3, ::3],
+            "sim_crops_mean": crops.mean(axis=(1, 2), dtype=np.float64).astype(np.float32)}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     cfg = Config(os.path.join(CODE, "ReID_net", "configs", "run"))
     cfg.initialize()
     arrays, shapes, requested = run_network(cfg)
     arrays.update(run_crops(cfg))
+    arrays.update(run_similarity_crops(cfg))
     g = {"weights": f"oracle.reid_oracle.synth_weights({SEED})", "input": f"default_rng({SEED}).standard_normal(({N_CROPS},128,128,3), float32)",
          "layer_shapes": shapes, "variables": [[n, list(s)] for n, s in requested],
          "config": {k: cfg._entries[k] for k in ("input_size", "num_classes", "context_region_factor", "output_embedding_layer")},

@@ -85,6 +85,9 @@ class T:
     def get_shape(self):
         return self.shape
 
+    def set_shape(self, shape):          # static-shape annotation: nothing to do for an eager array
+        pass
+
     def _b(self, o, f, rev=False):
         o = _np(o, self.a)
         return T(f(o, self.a) if rev else f(self.a, o))
