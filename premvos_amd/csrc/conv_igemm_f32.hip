@@ -362,6 +362,7 @@ bool conv_wino_applicable(const premvos_conv_desc& d);        // conv_wino_f32.h
 long conv_wino_workspace_bytes(const premvos_conv_desc& d);
 int conv_wino(const premvos_conv_desc& d, hipStream_t s);
 int conv_wino_fused(const premvos_conv_desc& d, hipStream_t s);
+bool conv_wino_fused_applicable(const premvos_conv_desc& d);
 bool conv_smalln_applicable(const premvos_conv_desc& d);      // conv_smalln_f32.hip
 int conv_smalln(const premvos_conv_desc& d, hipStream_t s);
 int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin) {
@@ -551,8 +552,8 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
     return premvos::conv_wino(d, s);
   }
   if (d.tile_hint == 3) {      // ... the slab-free variant of it (no workspace, one kernel); stage_k = block id
-    PV_REQUIRE(premvos::conv_wino_applicable(d), "conv2d: Winograd needs a 3x3 / stride 1 / dilation 1 fp32 layer with cout %% 4 == 0, "
-               "symmetric padding and packed filter transforms (wgt_wino)");
+    PV_REQUIRE(premvos::conv_wino_fused_applicable(d), "conv2d: Winograd needs a 3x3 / stride 1 fp32 layer with cout %% 4 == 0, symmetric "
+               "padding (= the dilation for atrous layers) and packed filter transforms (wgt_wino)");
     return premvos::conv_wino_fused(d, s);
   }
   // 1- and 2-channel heads: per-pixel dot products, not GEMM tiles (tile_hint 0 = auto, 1 = forced; any other hint

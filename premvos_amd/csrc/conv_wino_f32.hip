@@ -215,6 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
   const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
   const int tpi = tiles_y * tiles_x;
   const int Mt = p.n * tpi;
+  const int dil = p.dh;                                     // == p.dw (checked by the launcher)
   int tile_m, tile_n;
   {
     const int nwg = gridDim.x, id = blockIdx.x;
@@ -236,13 +237,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
     const int mm = rok ? m : 0;
     const int n = mm / tpi, rem = mm - n * tpi;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int y0 = 2 * ty - p.pt, x0 = 2 * tx - p.pl;
+    // atrous layers (dilation d, stride 1): the conv is an ordinary 3x3 conv on each of the d x d sub-lattices of the map;
+    // tile row ty addresses (residue ty % d, lattice tile ty / d), its outputs and its 4x4 patch are d pixels apart
+    const int y0 = (ty % dil) + 2 * (ty / dil) * dil - p.pt, x0 = (tx % dil) + 2 * (tx / dil) * dil - p.pl;
     boff[i] = (((long)n * p.h + y0) * p.w + x0) * p.in_ps;
     vy[i] = vx[i] = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      vy[i] |= (rok && (unsigned)(y0 + t) < (unsigned)p.h) ? 1u << t : 0u;
-      vx[i] |= ((unsigned)(x0 + t) < (unsigned)p.w) ? 1u << t : 0u;
+      vy[i] |= (rok && (unsigned)(y0 + t * dil) < (unsigned)p.h) ? 1u << t : 0u;
+      vx[i] |= ((unsigned)(x0 + t * dil) < (unsigned)p.w) ? 1u << t : 0u;
     }
   }
   unsigned wbase[B_PER_T];                   // element offsets (the launcher refuses tensors past 2^30 elements)
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
         for (int b = 0; b < 2; ++b) {
           const bool in = ((vy[i] >> ia[a]) & 1u) && ((vx[i] >> jb[b]) & 1u);
           okm[i] |= in ? 1u << (a * 2 + b) : 0u;
-          src[i][a * 2 + b] = in ? (unsigned)(boff[i] + ((long)ia[a] * p.w + jb[b]) * p.in_ps) : 0u;
+          src[i][a * 2 + b] = in ? (unsigned)(boff[i] + ((long)ia[a] * dil * p.w + jb[b] * dil) * p.in_ps) : 0u;
         }
     }
 #pragma unroll
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
               if (m >= Mt || col >= p.cout) continue;
               const int n = m / tpi, rem = m - n * tpi;
               const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-              const int oy = 2 * ty + ya, ox = 2 * tx + yb;
+              const int oy = (ty % dil) + (2 * (ty / dil) + ya) * dil, ox = (tx % dil) + (2 * (tx / dil) + yb) * dil;
               if (oy >= p.ho || ox >= p.wo) continue;
               const long pix = ((long)n * p.ho + oy) * p.wo + ox;
               float4 v = *reinterpret_cast<const float4*>(&stg[row * EP + c4 * 4]);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
       for (int ya = 0; ya < 2; ++ya)
 #pragma unroll
         for (int yb = 0; yb < 2; ++yb) {
-          const int oy = 2 * ty + ya, ox = 2 * tx + yb;
+          const int oy = (ty % dil) + (2 * (ty / dil) + ya) * dil, ox = (tx % dil) + (2 * (tx / dil) + yb) * dil;
           if (oy >= p.ho || ox >= p.wo) continue;
           const long pix = ((long)n * p.ho + oy) * p.wo + ox;
 #pragma unroll
@@ -544,6 +547,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const premvos_conv_des
 
 namespace premvos {
 
+// the slab-free kernel also takes atrous layers (dilation d, pad d: 'SAME'): Winograd on the d x d sub-lattices
+bool conv_wino_fused_applicable(const premvos_conv_desc& d) {
+  return d.wgt_wino != nullptr && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == d.dw && d.dh >= 1 &&
+         d.out_mode == PREMVOS_OUT_NHWC && d.precision == PREMVOS_PREC_F32 && d.cout % 4 == 0 && d.k_pad >= d.cin_pad &&
+         d.ho == d.h + 2 * d.pt - 2 * d.dh && d.wo == d.w + 2 * d.pl - 2 * d.dw && d.pt >= 0 && d.pl >= 0 &&
+         (d.dh == 1 || (d.pt == d.dh && d.pl == d.dw));
+}
+
 bool conv_wino_applicable(const premvos_conv_desc& d) {
   return d.wgt_wino != nullptr && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == 1 && d.dw == 1 &&
          d.out_mode == PREMVOS_OUT_NHWC && d.precision == PREMVOS_PREC_F32 && d.cout % 4 == 0 && d.k_pad >= d.cin_pad &&
@@ -595,7 +606,8 @@ static int launch_wino(const premvos_conv_desc& d, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int KB>
 static int launch_wino_fused(const premvos_conv_desc& d, hipStream_t s) {
-  const int ty = (d.ho + 1) / 2, tx = (d.wo + 1) / 2;
+  // virtual tile rows / columns: the dil residues of a coordinate interleaved, ceil(ceil(extent / dil) / 2) lattice tiles each
+  const int ty = d.dh * ((cdiv(d.ho, d.dh) + 1) / 2), tx = d.dw * ((cdiv(d.wo, d.dw) + 1) / 2);
   const long mt = (long)d.n * ty * tx;
   premvos_conv_desc w = d;
   w.k_pad = cdiv((int)d.cin_pad, 16) * 16;              // (a 32-deep stage zero-fills past it)
@@ -616,7 +628,8 @@ static int launch_wino_fused(const premvos_conv_desc& d, hipStream_t s) {
 // 2 = 64x128 / 4 / 16, 3 = 64x64 / 4 / 16, 4 = 64x128 / 4 / 32, 5 = 64x64 / 4 / 32, 6 = 128x128 / 8 / 32 (measured and dropped:
 // 128x64 / 4 / 16, 128x32 / 4 / 32, 128x64 / 8 / 32 -- never the fastest on the pipeline's layers)
 int conv_wino_fused(const premvos_conv_desc& d, hipStream_t s) {
-  if ((long)d.n * ((d.ho + 1) / 2) * ((d.wo + 1) / 2) >= (1L << 27)) return fail(PREMVOS_EINVAL, "conv2d(winograd): too many tiles");
+  if ((long)d.n * (d.dh * ((cdiv(d.ho, d.dh) + 1) / 2)) * (d.dw * ((cdiv(d.wo, d.dw) + 1) / 2)) >= (1L << 27))
+    return fail(PREMVOS_EINVAL, "conv2d(winograd): too many tiles");
   if ((long)d.n * d.h * d.w * d.in_ps >= (1L << 30) || 16L * d.cout_pad * (cdiv((int)d.cin_pad, 16) * 16) >= (1L << 30))
     return fail(PREMVOS_EINVAL, "conv2d(winograd, fused): 32-bit operand offsets need tensors below 2^30 elements");
   switch (d.stage_k) {

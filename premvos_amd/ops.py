@@ -247,6 +247,12 @@ def wino_applicable(d: ConvDesc) -> bool:
         and d.out_mode == OUT_NHWC and d.cout % 4 == 0 and d.ho == d.h + 2 * d.pt - 2 and d.wo == d.w + 2 * d.pl - 2
 
 
+def wino_atrous_applicable(d: ConvDesc) -> bool:
+    """3x3 / stride 1 / dilation r / pad r ('SAME'): Winograd on the r x r sub-lattices (slab-free kernel only)."""
+    return bool(d.wgt_wino) and d.precision == _lib.PREC_F32 and (d.kh, d.kw, d.sh, d.sw) == (3, 3, 1, 1) and d.dh == d.dw > 1 \
+        and d.out_mode == OUT_NHWC and d.cout % 4 == 0 and (d.pt, d.pl) == (d.dh, d.dw) and (d.ho, d.wo) == (d.h, d.w)
+
+
 def _candidates(d: ConvDesc):
     m = d.n * d.ho * d.wo
     if d.cout <= 32:
@@ -267,8 +273,9 @@ def _candidates(d: ConvDesc):
         out.append((2, 0, -1, 0, 0))               # tile_hint 2 = Winograd F(2x2,3x3) (csrc/conv_wino_f32.hip), 128 tile rows
         if d.cout > 32:
             out.append((2, 64, -1, 0, 0))          # ... with 64-tile-row workgroups
+    if wino_applicable(d) or wino_atrous_applicable(d):
         # tile_hint 3 = the same algebra without slabs: one kernel, a workgroup walks all 16 components of its block
-        # (stage_k = block id, see conv_wino_f32.hip: tile rows x couts / waves / stage depth)
+        # (stage_k = block id, see conv_wino_f32.hip: tile rows x couts / waves / stage depth); it also takes atrous layers
         if os.environ.get("PREMVOS_WINOGRAD_FUSED", "1") != "0":
             out.extend((3, v, -1, 0, 0) for v in (() if d.cout <= 32 else (3, 5) if d.cout <= 64 else (0, 2, 4, 6)))
     for bm, bn in tiles:

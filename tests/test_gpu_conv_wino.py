@@ -61,6 +61,28 @@ def test_winograd_matches_torch_and_the_gemm_kernel(n, cin, cout, h, w, act, res
         assert (outs[f"fused{v}"] - outs["wino"]).abs().max().item() < 2e-5 * scale, v
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,dil", [(2, 128, 128, 32, 40, 2), (1, 96, 64, 37, 29, 4), (1, 128, 96, 40, 56, 8), (1, 64, 128, 33, 50, 16)])
+def test_atrous_winograd_matches_torch(n, cin, cout, h, w, dil):
+    """Dilated 3x3 / pad = dilation layers (PWC-Net's context net, PWCNet.py:125-131) on the slab-free kernel: Winograd on the
+    dil x dil sub-lattices, every block."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin + dil)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=dil, dilation=dil), 0.1)
+    pk = ops.pack_conv(wt, b)
+    xin = _nhwc(x, ops)
+    scale = max(1.0, ref.abs().max().item())
+    for v in ((3, 5) if cout <= 64 else FUSED):
+        out = ops.NHWC.alloc(n, h, w, cout)
+        ops.conv2d(xin, pk, out, pad=(dil, dil), dilation=(dil, dil), act=ops.ACT_LEAKY, tile_hint=3, stage_k=v)
+        torch.cuda.synchronize()
+        assert (out.torch().cpu().double() - ref).abs().max().item() < 5e-5 * scale, v
+    d = ops.conv_desc(xin, pk, ops.NHWC.alloc(n, h, w, cout), pad=(dil, dil), dilation=(dil, dil))
+    assert any(c[0] == 3 for c in ops._candidates(d)) and not any(c[0] == 2 for c in ops._candidates(d))
+
+
 def test_winograd_is_refused_where_it_does_not_apply():
     from premvos_amd import _lib
     ops = _ops()
