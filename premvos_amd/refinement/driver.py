@@ -188,16 +188,17 @@ class RefinementEngine:
         self.valid_data = _FeedData()
         self.trainer = _FeedTrainer(self)
 
-    def refine_frames(self, images, proposal_lists, lane: int = 0):
+    def refine_frames(self, images, proposal_lists, lane: int = 0, sidecar: bool = False):
         """Several frames of equal size at once: the crops of all of them form one batch (``RefinementNet.refine_group``).
         ``lane`` selects an independent workspace of the net, so calls on different lanes may run concurrently (each on the
-        calling thread's current stream)."""
+        calling thread's current stream).  ``sidecar``: instead of "segmentation" (COCO RLE) / "conf_score" (str) the proposals get
+        "mask_bits" (packed on the GPU, premvos_amd.sidecar layout) and "conf" (float32) -- the optional binary fast path."""
         live = [(im, pr) for im, pr in zip(images, proposal_lists) if pr]
         if not live:
             return proposal_lists
         if len(live) == 1 or max(len(pr) for _, pr in live) > self.max_boxes:
             for im, pr in live:
-                self.refine_frame(im, pr, lane=lane)
+                self.refine_frame(im, pr, lane=lane, sidecar=sidecar)
             return proposal_lists
         P = _bucket(max(len(pr) for _, pr in live))
         boxes = np.zeros((len(live), P, 4), np.float32)
@@ -209,13 +210,17 @@ class RefinementEngine:
         # only the valid slots of every frame are encoded (padded slots of short frames hold empty masks)
         valid = torch.tensor([g * P + i for g, (_, pr) in enumerate(live) for i in range(len(pr))], dtype=torch.int64,
                              device=self.net.device)
-        segs = _encode_on_gpu(p.mask_g.view(-1, *p.mask_g.shape[2:]).index_select(0, valid))   # run boundaries on the GPU
+        sel = p.mask_g.view(-1, *p.mask_g.shape[2:]).index_select(0, valid)
+        segs = _pack_on_gpu(sel) if sidecar else _encode_on_gpu(sel)                       # run boundaries / bit packing on the GPU
         conf = p.conf_g.cpu().numpy()
         k = 0
         for g, (_, pr) in enumerate(live):
             for i in range(len(pr)):
-                pr[i]["segmentation"] = segs[k]
-                pr[i]["conf_score"] = str(conf[g, i])
+                if sidecar:
+                    pr[i]["mask_bits"], pr[i]["conf"] = segs[k], conf[g, i]
+                else:
+                    pr[i]["segmentation"] = segs[k]
+                    pr[i]["conf_score"] = str(conf[g, i])
                 k += 1
         return proposal_lists
 
@@ -236,7 +241,7 @@ class RefinementEngine:
             conf[s:s + len(chunk)] = p.conf[:len(chunk)].cpu().numpy()
         return masks, post, conf
 
-    def refine_frame(self, image_rgb: np.ndarray, proposals: List[dict], lane: int = 0) -> List[dict]:
+    def refine_frame(self, image_rgb: np.ndarray, proposals: List[dict], lane: int = 0, sidecar: bool = False) -> List[dict]:
         if not proposals:
             return proposals
         boxes = _boxes_from_proposals(proposals)
@@ -246,10 +251,13 @@ class RefinementEngine:
             P = self.max_boxes if len(proposals) > self.max_boxes else _bucket(len(chunk))
             p = self.net.refine(frame, torch.from_numpy(chunk).to(self.net.device), max_boxes=P, lane=lane)
             conf = p.conf[:len(chunk)].cpu().numpy()
-            segs = _encode_on_gpu(p.mask[:len(chunk)])
+            segs = _pack_on_gpu(p.mask[:len(chunk)]) if sidecar else _encode_on_gpu(p.mask[:len(chunk)])
             for i in range(len(chunk)):
-                proposals[s + i]["segmentation"] = segs[i]
-                proposals[s + i]["conf_score"] = str(conf[i])
+                if sidecar:
+                    proposals[s + i]["mask_bits"], proposals[s + i]["conf"] = segs[i], conf[i]
+                else:
+                    proposals[s + i]["segmentation"] = segs[i]
+                    proposals[s + i]["conf_score"] = str(conf[i])
         return proposals
 
 
@@ -257,6 +265,23 @@ def _encode_on_gpu(masks: torch.Tensor) -> List[dict]:
     """COCO RLE of uint8 CUDA masks [n,H,W] (same strings as rle.encode; premvos_rle_boundaries_u8 + host differencing)."""
     from ..mergetrack import encode_masks
     return encode_masks(masks)
+
+
+def _pack_on_gpu(masks: torch.Tensor) -> np.ndarray:
+    """uint8 CUDA masks [n,H,W] -> packed bits [n, ceil(H*W/8)] on the host (premvos_mask_pack_bits_u8; one launch when a mask
+    is a whole number of bytes, else one per mask)."""
+    from .. import _lib
+    n, h, w = masks.shape
+    nbytes = (h * w + 7) // 8
+    m = masks.contiguous()
+    bits = torch.empty((n, nbytes), dtype=torch.uint8, device=m.device)
+    lib = _lib.load()
+    if (h * w) % 8 == 0:
+        _lib.check(lib.premvos_mask_pack_bits_u8(m.data_ptr(), n * h * w, bits.data_ptr(), _lib.current_stream()), "mask_pack_bits")
+    else:
+        for i in range(n):
+            _lib.check(lib.premvos_mask_pack_bits_u8(m[i].data_ptr(), h * w, bits[i].data_ptr(), _lib.current_stream()), "mask_pack_bits")
+    return bits.cpu().numpy()
 
 
 def _bucket(n: int) -> int:
@@ -291,7 +316,8 @@ def refinement_net_init(config_path: str = "refinement_net/configs/live") -> Ref
     return RefinementEngine(RefinementNet(w, infer_num_middle(w)))
 
 
-def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_dir: str, output_dir: str) -> int:
+def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_dir: str, output_dir: str,
+                      sidecar: Optional[bool] = None) -> int:
     """The batch stage: every <seq>/<frame>.json of bb_input_dir -> output_dir (same relative name).  Consecutive frames of
     equal size are refined as one batch of crops (every box is an independent example, FewShotSegmentationForwarder.py:104-110).
     Host work overlaps the GPU (premvos_amd.io_pipeline): JPEG decode + JSON parsing run ahead on a thread pool, groups
@@ -301,6 +327,9 @@ def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_d
     from .. import io_pipeline as iop
     group = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
     files = sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json")))
+    # optional binary fast path: <frame>.pmv with bit-packed masks instead of <frame>.json with RLE strings;
+    # read by this package's ReID stage, `python -m premvos_amd.sidecar --to-json` gives MergeTrack its JSON back
+    sidecar = os.environ.get("PREMVOS_SIDECAR", "0") == "1" if sidecar is None else sidecar
 
     def load(jf):
         rel = os.path.relpath(jf, bb_input_dir)
@@ -326,17 +355,28 @@ def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_d
 
     def work(lane, jobs):
         if streams[lane] is None:
-            engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs])
+            engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], sidecar=sidecar)
         else:
             with torch.cuda.stream(streams[lane]):
-                engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], lane=lane)
+                engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], lane=lane, sidecar=sidecar)
                 streams[lane].synchronize()
         return jobs
 
     with iop.Writer(enabled=iop.io_threads() > 0) as writer:
         for jobs in iop.lanes(groups(), work, n_lanes):
-            writer.submit(_write_jobs, jobs)
+            writer.submit(_write_sidecars if sidecar else _write_jobs, jobs)
     return len(files)
+
+
+def _write_sidecars(jobs) -> None:
+    from .. import sidecar as sc
+    for out_fn, image, proposals in jobs:
+        os.makedirs(os.path.dirname(out_fn), exist_ok=True)
+        h, w = image.shape[:2]
+        n = len(proposals)
+        sc.write(os.path.splitext(out_fn)[0] + sc.EXT, h, w, np.array([p["bbox"] for p in proposals], np.float64).reshape(n, 4),
+                 np.array([p["score"] for p in proposals], np.float64), np.array([p["conf"] for p in proposals], np.float32),
+                 np.stack([p["mask_bits"] for p in proposals]) if n else np.zeros((0, (h * w + 7) // 8), np.uint8))
 
 
 def _write_jobs(jobs) -> None:

@@ -116,15 +116,23 @@ def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: st
     (premvos_amd.io_pipeline); the file contents equal the serial loop's."""
     from PIL import Image
     from .. import io_pipeline as iop
-    files = sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json")))
+    from .. import sidecar as sc
+    # <frame>.json (the reference's format) or, from this package's refinement stage with PREMVOS_SIDECAR=1, <frame>.pmv (bit-packed
+    # masks: no RLE string to parse); the output keeps the input's format
+    files = sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json")) + glob.glob(os.path.join(bb_input_dir, "*", "*" + sc.EXT)))
 
     def load(jf):
         rel = os.path.relpath(jf, bb_input_dir)
-        with open(jf) as f:
-            proposals = json.load(f)
+        if jf.endswith(sc.EXT):
+            d = sc.read(jf)
+            proposals = d
+            bbs = [sc.tight_bbox(m) for m in sc.unpack_masks(d)] if d["mask_bits"] is not None else []
+        else:
+            with open(jf) as f:
+                proposals = json.load(f)
+            bbs = [rle.to_bbox(p["segmentation"]) for p in proposals]
         boxes, idx = [], []
-        for i, p in enumerate(proposals):
-            bb = rle.to_bbox(p["segmentation"])
+        for i, bb in enumerate(bbs):
             if bb[2] <= 0 or bb[3] <= 0:
                 continue
             boxes.append(bb)
@@ -136,6 +144,9 @@ def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: st
 
     def dump(out_fn, proposals):
         os.makedirs(os.path.dirname(out_fn), exist_ok=True)
+        if isinstance(proposals, dict):                      # side-car in, side-car out
+            sc.write_dict(out_fn, proposals)
+            return
         with open(out_fn, "w") as f:
             json.dump(proposals, f)
 
@@ -144,8 +155,14 @@ def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: st
         for rel, proposals, boxes, idx, image in iop.prefetch(files, load):
             if boxes:
                 emb = engine.embed(image, boxes, feed=False)
-                for i, e in zip(idx, emb):
-                    proposals[i]["ReID"] = np.array(e).tolist()
+                if isinstance(proposals, dict):
+                    n_p = len(proposals["bbox"])
+                    proposals["reid"], proposals["has_reid"] = np.zeros((n_p, 128), np.float32), np.zeros(n_p, np.uint8)
+                    for i, e in zip(idx, emb):
+                        proposals["reid"][i], proposals["has_reid"][i] = np.asarray(e, np.float32), 1
+                else:
+                    for i, e in zip(idx, emb):
+                        proposals[i]["ReID"] = np.array(e).tolist()
             writer.submit(dump, os.path.join(output_dir, rel), proposals)
             n += 1
     return n

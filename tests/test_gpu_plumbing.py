@@ -235,3 +235,51 @@ def test_streaming_driver_writes_the_stage_drivers_tree(tmp_path, monkeypatch):
     assert fa == fb and len(fa) == 4 + 4 * 5
     for f in fa:
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
+
+
+def test_binary_side_car_holds_what_the_json_holds(tmp_path):
+    """PREMVOS_SIDECAR fast path: the refinement stage writes <frame>.pmv (bit-packed masks from the GPU, no RLE
+    strings), the ReID stage reads and extends it; converted back (premvos_amd.sidecar) every file is the JSON the default path
+    writes -- same floats, same RLE strings, same conf_score strings; ReID vectors agree to fp32 round-off of the batch."""
+    from PIL import Image
+    from premvos_amd import sidecar as sc
+    from premvos_amd.refinement import driver as rd
+    from premvos_amd.reid import driver as qd
+    from premvos_amd.reid import ReIDEngine, ReIDNet
+    h, w = 120, 200
+    rng = np.random.default_rng(3)
+    (tmp_path / "img" / "seq").mkdir(parents=True)
+    (tmp_path / "bb" / "seq").mkdir(parents=True)
+    for t in range(3):
+        pair = O.synth_frame_pair(h, w, seed=41, shift=(2.0 * t, 1.0 * t))
+        img = (pair[0, 3:, :, :w].permute(1, 2, 0) * 255).round().to(torch.uint8).numpy()
+        Image.fromarray(img).save(tmp_path / "img" / "seq" / f"{t:05d}.jpg", quality=95)
+        n = (5, 0, 3)[t]
+        props = [{"bbox": [round(float(x), 1) for x in (rng.uniform(0, 90), rng.uniform(0, 40), rng.uniform(30, 100), rng.uniform(30, 70))],
+                  "score": round(float(rng.uniform(0.5, 1)), 2)} for _ in range(n)]
+        (tmp_path / "bb" / "seq" / f"{t:05d}.json").write_text(json.dumps(props))
+    engine = rd.RefinementEngine(rd.RefinementNet(RO.synth_weights(1, MIDDLE), MIDDLE))
+    args = (str(tmp_path / "img") + "/", str(tmp_path / "bb") + "/")
+    assert rd.forward_directory(engine, *args, str(tmp_path / "ref_json") + "/", sidecar=False) == 3
+    assert rd.forward_directory(engine, *args, str(tmp_path / "ref_pmv") + "/", sidecar=True) == 3
+    assert sorted(os.listdir(tmp_path / "ref_pmv" / "seq")) == [f"{t:05d}{sc.EXT}" for t in range(3)]
+    assert sc.convert_tree(str(tmp_path / "ref_pmv"), str(tmp_path / "ref_back")) == 3
+    for t in range(3):
+        a = (tmp_path / "ref_json" / "seq" / f"{t:05d}.json").read_text()
+        b = (tmp_path / "ref_back" / "seq" / f"{t:05d}.json").read_text()
+        assert a == b, t                                                   # byte for byte
+    assert os.path.getsize(tmp_path / "ref_pmv" / "seq" / "00000.pmv") == 24 + 5 * (32 + 8 + 4 + h * w // 8)
+    # ReID stage on either format
+    q = ReIDEngine(ReIDNet(QO.synth_weights(0, REID_UNITS), units=[(n_, f, k, s) for n_, _, f, k, s in REID_UNITS]))
+    assert qd.forward_directory(q, args[0], str(tmp_path / "ref_json") + "/", str(tmp_path / "reid_json") + "/") == 3
+    assert qd.forward_directory(q, args[0], str(tmp_path / "ref_pmv") + "/", str(tmp_path / "reid_pmv") + "/") == 3
+    sc.convert_tree(str(tmp_path / "reid_pmv"), str(tmp_path / "reid_back"))
+    for t in range(3):
+        a = json.load(open(tmp_path / "reid_json" / "seq" / f"{t:05d}.json"))
+        b = json.load(open(tmp_path / "reid_back" / "seq" / f"{t:05d}.json"))
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert {k: v for k, v in x.items() if k != "ReID"} == {k: v for k, v in y.items() if k != "ReID"}
+            assert ("ReID" in x) == ("ReID" in y)
+            if "ReID" in x:
+                assert np.abs(np.array(x["ReID"]) - np.array(y["ReID"])).max() < 1e-5 * max(1.0, np.abs(x["ReID"]).max())
