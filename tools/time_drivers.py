@@ -45,6 +45,9 @@ for rep in ("cold", "warm"):            # cold = plan building + autotuning incl
         q_eng = qd.engine_from_config(qd.Config("code/ReID_net/configs/run"))
     stage_time(f"refinement/{rep}", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_proposals/"))
     stage_time(f"reid/{rep}", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_proposals/", f"{inter}/ReID_proposals/"))
+# the optional binary side-car (PREMVOS_SIDECAR=1): refinement writes <frame>.pmv (bit-packed masks), ReID reads it
+stage_time("refinement(side-car)/warm", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_sidecar/", sidecar=True))
+stage_time("reid(side-car)/warm", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_sidecar/", f"{inter}/ReID_sidecar/"))
 # the four hot-path stages as ONE streaming process (one decode per frame, stages overlapped on three host threads)
 from premvos_amd import stream
 sp = stream.StreamPipeline("weights/pwc.pth.tar", "weights/general.pt", "weights/specific.pt", "weights/refine.pt",
