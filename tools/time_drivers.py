@@ -48,6 +48,8 @@ for rep in ("cold", "warm"):            # cold = plan building + autotuning incl
 # the optional binary side-car (PREMVOS_SIDECAR=1): refinement writes <frame>.pmv (bit-packed masks), ReID reads it
 stage_time("refinement(side-car)/warm", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_sidecar/", sidecar=True))
 stage_time("reid(side-car)/warm", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_sidecar/", f"{inter}/ReID_sidecar/"))
+del r_eng, q_eng                          # (their plans hold tens of GB of activations; the streaming pipeline builds its own)
+import gc; gc.collect(); torch.cuda.empty_cache()
 # the four hot-path stages as ONE streaming process (one decode per frame, stages overlapped on three host threads)
 from premvos_amd import stream
 sp = stream.StreamPipeline("weights/pwc.pth.tar", "weights/general.pt", "weights/specific.pt", "weights/refine.pt",
