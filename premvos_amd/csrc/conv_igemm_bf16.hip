@@ -282,13 +282,13 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   dim3 grid(premvos::cdiv(M, BM), premvos::cdiv(d.cout, BN));
   dim3 block(64 * WM * WN);
   constexpr int LDS_BYTES = 2 * (NPASS == 3 ? 2 : 1) * (BM + BN) * (KB * 2 + 16);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static const bool attr_done = [] {            // once per instantiation, thread-safe
     allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, true, KB>, LDS_BYTES);
     allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, true, false, KB>, LDS_BYTES);
     allow_lds(conv_igemm_bf16_kernel<BM, BN, WM, WN, NPASS, false, false, KB>, LDS_BYTES);
-    attr_done = true;
-  }
+    return true;
+  }();
+  (void)attr_done;
   int splits = pick_splits(d, BM, BN);
   const int KT = d.k_pad / KB;
   if (splits > 1) {

@@ -418,15 +418,15 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   dim3 grid(premvos::cdiv(M, BM), premvos::cdiv(d.cout, BN));
   dim3 block(64 * WM * WN);
   constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static const bool attr_done = [] {            // once per instantiation, thread-safe (the file drivers launch from several threads)
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB, true>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, false, KB, true>, LDS_BYTES);
-    attr_done = true;
-  }
+    return true;
+  }();
+  (void)attr_done;
   const bool pw = d.kh == 1 && d.kw == 1 && d.pt == 0 && d.pl == 0;
   int splits = pick_splits(d, BM, BN, KB);
   const int KT = premvos::cdiv(d.k_pad, KB);

@@ -587,12 +587,12 @@ static int launch_wino(const premvos_conv_desc& d, hipStream_t s) {
   w.k_pad = cdiv((int)d.cin_pad, 16) * 16;              // the transformed filters are packed with k = cin only
   const int m_tiles = cdiv((int)mt, BM);
   constexpr int LDS_BYTES = 2 * (BM + BN) * RS * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static const bool attr_done = [] {            // once per instantiation, thread-safe
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS_BYTES);
-    attr_done = true;
-  }
+    return true;
+  }();
+  (void)attr_done;
   hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles * 16), dim3(256), LDS_BYTES, s, w, d.wgt_wino,
                      d.workspace, ty, tx, m_tiles, n_tiles);
   int rc = check_launch("wino_gemm");
@@ -613,12 +613,12 @@ static int launch_wino_fused(const premvos_conv_desc& d, hipStream_t s) {
   w.k_pad = cdiv((int)d.cin_pad, 16) * 16;              // (a 32-deep stage zero-fills past it)
   const int m_tiles = cdiv((int)mt, BM), n_tiles = cdiv(d.cout, BN);
   constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static const bool attr_done = [] {            // once per instantiation, thread-safe
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_kernel<BM, BN, WM, WN, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS_BYTES);
-    attr_done = true;
-  }
+    return true;
+  }();
+  (void)attr_done;
   hipLaunchKernelGGL((wino_fused_kernel<BM, BN, WM, WN, KB>), dim3(m_tiles * n_tiles), dim3(64 * WM * WN), LDS_BYTES, s, w, d.wgt_wino, ty, tx,
                      m_tiles, n_tiles);
   return check_launch("wino_fused");

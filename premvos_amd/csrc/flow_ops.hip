@@ -338,16 +338,18 @@ extern "C" int premvos_flow_postprocess_f32(const float* flow2, int32_t flow_ps,
 // Host utility (no GPU): CRC-32C (Castagnoli) of a buffer, the checksum of TF tensor-bundle checkpoints
 // (premvos_amd/weights.py reads/writes them without TensorFlow).  Byte-wise table, ~1 GB/s.
 extern "C" uint32_t premvos_crc32c_host(const void* data, int64_t n) {
-  static uint32_t table[256];
-  static bool init = false;
-  if (!init) {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-      table[i] = c;
+  struct Table {
+    uint32_t v[256];
+    Table() {
+      for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        v[i] = c;
+      }
     }
-    init = true;
-  }
+  };
+  static const Table tbl;                       // built once, thread-safe (the loaders of two engines may run side by side)
+  const uint32_t* table = tbl.v;
   const uint8_t* p = static_cast<const uint8_t*>(data);
   uint32_t c = 0xFFFFFFFFu;
   for (int64_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
