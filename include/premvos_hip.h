@@ -30,6 +30,7 @@ extern "C" {
 #define PREMVOS_OK 0
 #define PREMVOS_EINVAL (-1)
 #define PREMVOS_ELAUNCH (-2)
+#define PREMVOS_EUNSUPPORTED (-3) /* valid input outside what the entry point covers (premvos_jpeg_*: the caller falls back) */
 
 /* activation enum for the fused conv epilogue */
 #define PREMVOS_ACT_NONE 0
@@ -269,6 +270,37 @@ int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void*
 /* Host-side utility (no GPU work): CRC-32C of a host buffer -- the checksum of TensorFlow tensor-bundle checkpoints,
  * which premvos_amd/weights.py reads and writes without TensorFlow (proposal_net/train.py:655, core/Saver.py:33-48). */
 uint32_t premvos_crc32c_host(const void* data, int64_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Optional GPU JPEG decode.  Replaces the image readers of the stages -- cv2.imread
+ * (proposal_net/train.py:500, BGR), scipy.ndimage.imread / PIL (optical_flow_net-PWC-Net/script_pwc_multi.py:34,
+ * ReID_net/prepare_input.py:38, RGB) -- i.e. libjpeg(-turbo) with its defaults: JDCT_ISLOW, fancy up-sampling, YCbCr -> RGB.
+ * Baseline / extended-sequential Huffman files, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, one interleaved scan, restart
+ * intervals; anything else returns PREMVOS_EUNSUPPORTED and the caller keeps its default reader.  The output is the
+ * library's, byte for byte.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct premvos_jpeg_info {
+  int32_t width, height, ncomp;  /* ncomp 1 (grey) or 3 (YCbCr) */
+  int32_t hs, vs;                /* luma samples per chroma sample: 1x1, 2x1 or 2x2 (1x1 for grey) */
+  int32_t mcux, mcuy;            /* MCU grid: ceil(width / (8 hs)) x ceil(height / (8 vs)) */
+  int32_t blocks_w[3], blocks_h[3];
+  int32_t reserved;
+  int64_t coef_offset[3];        /* int16 elements: component c holds [blocks_h][blocks_w][64] quantised coefficients, row-major */
+  int64_t coef_count;            /* total int16 elements */
+  uint16_t quant[3][64];         /* quantisation table of each component, row-major (de-zig-zagged) */
+} premvos_jpeg_info;
+
+/* HOST function, no GPU work: marker parsing + Huffman decoding (ITU-T T.81 F.2).  coef == NULL: header only (fills *info).
+ * Otherwise coef (host memory, any alignment; pinned for an asynchronous upload) receives info->coef_count values. */
+int premvos_jpeg_entropy_decode_host(const uint8_t* data, int64_t n, premvos_jpeg_info* info, int16_t* coef,
+                                     int64_t coef_capacity);
+/* bytes of the device workspace (the component planes between the two kernels) */
+int64_t premvos_jpeg_workspace_bytes(const premvos_jpeg_info* info);
+/* coef: DEVICE copy of the coefficients (16-byte aligned); info: the host struct; out: uint8 [height][width][3],
+ * RGB (bgr = 0) or BGR (bgr != 0, what cv2.imread returns).  De-quantisation + jidctint.c inverse DCT, then
+ * jdsample.c fancy up-sampling fused with jdcolor.c's colour conversion. */
+int premvos_jpeg_reconstruct_u8(const int16_t* coef, const premvos_jpeg_info* info, void* workspace, uint8_t* out,
+                                int32_t bgr, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * ReID embedding net (code/ReID_net).  Its convs / FC layers go through premvos_conv2d_f32, the pool

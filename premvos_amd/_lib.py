@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 6          # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
+ABI_VERSION = 7          # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NHWC, OUT_PIXSHUF2 = 0, 1
@@ -68,6 +68,8 @@ SIGNATURES = {
     "premvos_broadcast_pixel_f32": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "premvos_refine_output_f32": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "premvos_mfma_f32_calibrate": [C.c_int64, _i32, _vp, _vp],
+    "premvos_jpeg_entropy_decode_host": [_vp, C.c_int64, _vp, _vp, C.c_int64],
+    "premvos_jpeg_reconstruct_u8": [_vp, _vp, _vp, _vp, _i32, _vp],
     "premvos_reid_input_u8": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
     "premvos_scale_shift_relu_f32": [_vp, _i32, C.c_int64, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "premvos_mask_warp_u8": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp],
@@ -134,6 +136,8 @@ def load():
     lib.premvos_rle_counts_to_string_host.restype = C.c_int64
     lib.premvos_rle_workspace_bytes.argtypes = [_i32, _i32, _i32]
     lib.premvos_rle_workspace_bytes.restype = C.c_int64
+    lib.premvos_jpeg_workspace_bytes.argtypes = [_vp]
+    lib.premvos_jpeg_workspace_bytes.restype = C.c_int64
     _LIB = lib
     return lib
 

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, jpeg, ops
 from .pwcnet import PWCDCNet, pwc_dc_net
 
 TAG_FLOAT = 202021.25
@@ -182,13 +182,15 @@ def main(argv: Optional[List[str]] = None) -> int:
         pairs = list(zip(images[:-1], images[1:], outs))
         # frames are decoded ahead on a thread pool (every frame once), the .flo files are written by a background thread;
         # the main thread only feeds the GPU.  Same bytes as the serial loop of the reference (:94-102).
-        decoded = iop.prefetch(images, lambda fn: _imread_rgb(fn)[:, :, :3])
-        frames: Dict[str, np.ndarray] = {}
+        decoded = iop.prefetch(images, jpeg.loader())       # (PREMVOS_GPU_JPEG=1: entropy decode here, the rest on the GPU)
+        frames: Dict[str, object] = {}
 
         def frame(fn):
             while fn not in frames:
                 k = images[len(frames) + frame.dropped]
-                frames[k] = next(decoded)
+                fr = next(decoded)
+                # a frame is the second image of one pair and the first of the next: a GPU-decoded frame is finished once
+                frames[k] = jpeg.to_device(fr) if isinstance(fr, jpeg.Decoded) else fr
             return frames[fn]
         frame.dropped = 0
         for s0 in range(0, len(pairs), batch):
@@ -202,8 +204,8 @@ def main(argv: Optional[List[str]] = None) -> int:
                 if len(g) not in stages:
                     stages[len(g)] = FlowStage(net=net, batch=len(g))
                 st = stages[len(g)]
-                im1 = torch.from_numpy(np.stack([frames[a] for a, _, _ in g])).to(st.device)
-                im2 = torch.from_numpy(np.stack([frames[b_] for _, b_, _ in g])).to(st.device)
+                im1 = jpeg.stack_frames([frames[a] for a, _, _ in g], st.device)
+                im2 = jpeg.stack_frames([frames[b_] for _, b_, _ in g], st.device)
                 flo = st.run(im1, im2).cpu().numpy()
                 for k, (_, _, flow_fn) in enumerate(g):
                     writer.submit(writeFlowFile, flow_fn, flo[k])

@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, jpeg, ops
 from .model import (RESNET_NUM_BLOCK, RESULTS_PER_IM, TEST_POST_NMS_TOPK, ProposalNet)
 
 SHORT_EDGE_SIZE, MAX_SIZE = 800, 1333      # config.py:64-65
@@ -239,7 +239,12 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
     batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "1")))     # measured: host decode dominates, 1 is fastest
     from .. import io_pipeline as iop
 
+    fast = isinstance(pred_func, OfflinePredictor) and not pred_func.net.mode_mask
+    gpu_jpeg = fast and jpeg.enabled()            # entropy decode on the pool, inverse DCT / colour conversion on the GPU (BGR)
+
     def load(job):
+        if gpu_jpeg:
+            return job[1], jpeg.host_stage(job[0])
         img = np.asarray(Image.open(job[0]).convert("RGB"))[:, :, ::-1]             # cv2.imread gives BGR (train.py:500)
         return job[1], np.ascontiguousarray(img)
 
@@ -261,9 +266,9 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
             if not chunk:
                 break
             orig = chunk[0][1].shape[:2]
-            if isinstance(pred_func, OfflinePredictor) and not pred_func.net.mode_mask:
+            if fast:
                 stage = _stage_for(pred_func.net, len(chunk))
-                stage.run(torch.from_numpy(np.stack([c[1][:, :, :3] for c in chunk])).to(stage.device))
+                stage.run(jpeg.stack_frames([c[1] for c in chunk], stage.device, bgr=gpu_jpeg))   # (host arrays are BGR already)
                 results = stage.json_results(orig)
             else:
                 results = [convert_results_to_json(detect_one_image(c[1], pred_func)) for c in chunk]

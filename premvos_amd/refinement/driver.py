@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .. import rle
+from .. import jpeg, rle
 from .model import RefinementNet
 
 
@@ -204,7 +204,7 @@ class RefinementEngine:
         boxes = np.zeros((len(live), P, 4), np.float32)
         for g, (_, pr) in enumerate(live):
             boxes[g, :len(pr)] = _boxes_from_proposals(pr)
-        frames = torch.from_numpy(np.stack([np.array(im[:, :, :3], dtype=np.uint8, order="C") for im, _ in live])).to(self.net.device)
+        frames = jpeg.stack_frames([im for im, _ in live], self.net.device)
         counts = torch.tensor([len(pr) for _, pr in live], dtype=torch.int32, device=self.net.device)
         p = self.net.refine_group(frames, torch.from_numpy(boxes).to(self.net.device), counts, lane=lane)
         # only the valid slots of every frame are encoded (padded slots of short frames hold empty masks)
@@ -245,7 +245,7 @@ class RefinementEngine:
         if not proposals:
             return proposals
         boxes = _boxes_from_proposals(proposals)
-        frame = torch.from_numpy(np.array(image_rgb[:, :, :3], dtype=np.uint8, order="C")).to(self.net.device)
+        frame = jpeg.to_device(image_rgb, self.net.device)
         for s in range(0, len(proposals), self.max_boxes):
             chunk = boxes[s:s + self.max_boxes]
             P = self.max_boxes if len(proposals) > self.max_boxes else _bucket(len(chunk))
@@ -330,12 +330,13 @@ def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_d
     # optional binary fast path: <frame>.pmv with bit-packed masks instead of <frame>.json with RLE strings;
     # read by this package's ReID stage, `python -m premvos_amd.sidecar --to-json` gives MergeTrack its JSON back
     sidecar = os.environ.get("PREMVOS_SIDECAR", "0") == "1" if sidecar is None else sidecar
+    read_frame = jpeg.loader()                    # PIL on the host, or (PREMVOS_GPU_JPEG=1) entropy decode here + the rest on the GPU
 
     def load(jf):
         rel = os.path.relpath(jf, bb_input_dir)
         with open(jf) as f:
             proposals = json.load(f)
-        image = np.asarray(Image.open(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")).convert("RGB"))
+        image = read_frame(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg"))
         return os.path.join(output_dir, rel), image, proposals
 
     def groups():

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .. import rle
+from .. import jpeg, rle
 from ..refinement.driver import Config as _TypedConfig
 from .model import ReIDNet
 
@@ -74,7 +74,7 @@ class ReIDEngine:
     def embed(self, image_rgb: np.ndarray, boxes_xywh, feed: bool) -> np.ndarray:
         boxes = np.asarray(boxes_xywh, np.float32).reshape(-1, 4)
         out = np.zeros((len(boxes), 128), np.float32)
-        frame = torch.from_numpy(np.array(image_rgb[:, :, :3], dtype=np.uint8, order="C")).to(self.net.device)
+        frame = jpeg.to_device(image_rgb, self.net.device)
         for s in range(0, len(boxes), self.max_boxes):
             chunk = boxes[s:s + self.max_boxes]
             P = self.max_boxes if len(boxes) > self.max_boxes else _bucket(len(chunk))
@@ -120,6 +120,7 @@ def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: st
     # <frame>.json (the reference's format) or, from this package's refinement stage with PREMVOS_SIDECAR=1, <frame>.pmv (bit-packed
     # masks: no RLE string to parse); the output keeps the input's format
     files = sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json")) + glob.glob(os.path.join(bb_input_dir, "*", "*" + sc.EXT)))
+    read_frame = jpeg.loader()                    # PIL on the host, or (PREMVOS_GPU_JPEG=1) entropy decode here + the rest on the GPU
 
     def load(jf):
         rel = os.path.relpath(jf, bb_input_dir)
@@ -139,7 +140,7 @@ def forward_directory(engine: ReIDEngine, image_input_dir: str, bb_input_dir: st
             idx.append(i)
         image = None
         if boxes:
-            image = np.asarray(Image.open(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg")).convert("RGB"))
+            image = read_frame(os.path.join(image_input_dir, os.path.splitext(rel)[0] + ".jpg"))
         return rel, proposals, boxes, idx, image
 
     def dump(out_fn, proposals):

@@ -30,6 +30,7 @@ import numpy as np
 import torch
 
 from . import io_pipeline as iop
+from . import jpeg
 
 _END = object()
 
@@ -75,7 +76,7 @@ class StreamPipeline:
             self.nets.append(pd.ProposalNet(w, num_blocks=pd.infer_num_blocks(w), use_graph=False))
         rw = rd.load_weights(refinement_weights)
         self.engine = rd.RefinementEngine(rd.RefinementNet(rw, rd.infer_num_middle(rw), use_graph=False))
-        self.streams = {k: torch.cuda.Stream(device=self.dev) for k in ("flow", "prop0", "prop1", "ref")}
+        self.streams = {k: torch.cuda.Stream(device=self.dev) for k in ("flow", "prop0", "prop1", "ref", "decode")}
         self.flow_stages, self.prop_stages = {}, {}
 
     # ---- the stage bodies (each runs on its own host thread and HIP stream) ----------------------------------------
@@ -89,8 +90,8 @@ class StreamPipeline:
         with torch.cuda.stream(self.streams["flow"]):
             if n not in self.flow_stages:
                 self.flow_stages[n] = FlowStage(net=self.flow_net, batch=n, use_graph=False)
-            im1 = torch.from_numpy(np.stack(frames[:n])).to(self.dev)
-            im2 = torch.from_numpy(np.stack(second)).to(self.dev)
+            im1 = jpeg.stack_frames(frames[:n], self.dev)
+            im2 = jpeg.stack_frames(second, self.dev)
             flo = self.flow_stages[n].run(im1, im2).cpu().numpy()
         for k in range(n):
             fn = os.path.join(self.out, "flow", seq, names[k] + ".flo")
@@ -107,7 +108,7 @@ class StreamPipeline:
             if key not in self.prop_stages:
                 self.prop_stages[key] = pd.ProposalStage({}, batch=n, device=net.device, net=net, rgb_input=True, use_graph=False)
             st = self.prop_stages[key]
-            st.run(torch.from_numpy(np.stack(frames)).to(self.dev))
+            st.run(jpeg.stack_frames(frames, self.dev))
             lists = st.json_results(orig)
         sub = ("general_proposals", "specific_proposals")[which]
         for k in range(n):
@@ -132,7 +133,6 @@ class StreamPipeline:
 
     # ---- the driver ---------------------------------------------------------------------------------------------------
     def run_sequences(self, folders: List[str]) -> int:
-        from PIL import Image
         errors: List[BaseException] = []
         writer = iop.Writer(enabled=True)
         q_flow, q_g, q_s, q_rg, q_rs = (queue.Queue(maxsize=3) for _ in range(5))
@@ -160,7 +160,9 @@ class StreamPipeline:
         for video in folders:
             images = sorted(glob.glob(os.path.join(video, "*")))
             seq = video.rstrip("/").split("/")[-1]
-            decoded = iop.prefetch(images, lambda fn: np.ascontiguousarray(np.asarray(Image.open(fn).convert("RGB"))[:, :, :3]))
+            # PREMVOS_GPU_JPEG=1: the pool only Huffman-decodes; this thread finishes each frame ONCE on the GPU (inverse DCT,
+            # up-sampling, colour conversion) and the four stage threads share the HBM copy instead of uploading it each
+            decoded = iop.prefetch(images, jpeg.loader())
             names = [os.path.splitext(os.path.basename(fn))[0] for fn in images]
             cur: List[np.ndarray] = []
             cur_names: List[str] = []
@@ -176,6 +178,10 @@ class StreamPipeline:
             for name, fr in zip(names, decoded):
                 if errors:
                     break
+                if isinstance(fr, jpeg.Decoded):
+                    with torch.cuda.stream(self.streams["decode"]):
+                        fr = jpeg.to_device(fr, self.dev)
+                    self.streams["decode"].synchronize()
                 if pending is not None:
                     emit(pending[0], pending[1], fr)
                     pending = None

@@ -48,6 +48,11 @@ for rep in ("cold", "warm"):            # cold = plan building + autotuning incl
 # the optional binary side-car (PREMVOS_SIDECAR=1): refinement writes <frame>.pmv (bit-packed masks), ReID reads it
 stage_time("refinement(side-car)/warm", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_sidecar/", sidecar=True))
 stage_time("reid(side-car)/warm", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_sidecar/", f"{inter}/ReID_sidecar/"))
+# the optional GPU JPEG decode (PREMVOS_GPU_JPEG=1): the pool only Huffman-decodes, inverse DCT / colour conversion on the GPU
+os.environ["PREMVOS_GPU_JPEG"] = "1"
+os.system(f"rm -rf {root}/{inter}/flow")
+stage_time("flow(gpu-jpeg)/warm", lambda: fd.main(["seq_to_run.txt", "weights/pwc.pth.tar", f"{inter}/flow"]))
+os.environ["PREMVOS_GPU_JPEG"] = "0"
 del r_eng, q_eng                          # (their plans hold tens of GB of activations; the streaming pipeline builds its own)
 import gc; gc.collect(); torch.cuda.empty_cache()
 # the four hot-path stages as ONE streaming process (one decode per frame, stages overlapped on three host threads)
@@ -57,6 +62,11 @@ sp = stream.StreamPipeline("weights/pwc.pth.tar", "weights/general.pt", "weights
 for rep in ("cold", "warm", "warm2"):    # cold = plans built on the fly
     os.system(f"rm -rf {root}/output")
     stage_time(f"stream A+B+B+C+D/{rep}", lambda: sp.run_sequences(["data/DAVIS/JPEGImages/480p/seq/"]))
+os.environ["PREMVOS_GPU_JPEG"] = "1"
+for rep in ("warm", "warm2"):
+    os.system(f"rm -rf {root}/output")
+    stage_time(f"stream(gpu-jpeg)/{rep}", lambda: sp.run_sequences(["data/DAVIS/JPEGImages/480p/seq/"]))
+os.environ["PREMVOS_GPU_JPEG"] = "0"
 nprops = sum(len(json.load(open(f"{root}/{inter}/combined_proposals/seq/{i:05d}.json"))) for i in range(T)) / T
 print(f"{T} frames 480x854, {nprops:.1f} combined proposals per frame; DRIVER_BATCH={os.environ.get('PREMVOS_DRIVER_BATCH', 'default')}")
 for k, v in stamps.items():
@@ -64,6 +74,7 @@ for k, v in stamps.items():
 serial = sum(stamps[f"{k}/warm"] for k in ("flow", "general_proposals", "specific_proposals", "refinement"))
 summary = {"frames": T, "proposals_per_frame": round(nprops, 1),
            "stage_drivers_one_after_the_other_fps": round(T / serial, 2), "streaming_driver_fps": round(T / min(stamps["stream A+B+B+C+D/warm"], stamps["stream A+B+B+C+D/warm2"]), 2),
+           "streaming_driver_gpu_jpeg_fps": round(T / min(stamps["stream(gpu-jpeg)/warm"], stamps["stream(gpu-jpeg)/warm2"]), 2),
            "per_stage_fps": {k.split("/")[0]: round(T / v, 1) for k, v in stamps.items() if k.endswith("/warm")}}
 print(json.dumps(summary))
 if len(sys.argv) > 2:
