@@ -33,7 +33,8 @@ from premvos_amd.proposal.combine import combine
 from premvos_amd.refinement import driver as rd
 from premvos_amd.reid import driver as qd
 inter = "output/intermediate"
-for rep in ("cold", "warm"):            # cold = plan building + autotuning included; warm = second sequence-equivalent
+ONLY_STREAM = os.environ.get("TIME_DRIVERS_ONLY_STREAM") == "1"     # dev: skip the stage drivers
+for rep in (() if ONLY_STREAM else ("cold", "warm")):            # cold = plan building + autotuning included; warm = second sequence-equivalent
     os.system(f"rm -rf {root}/output")
     stage_time(f"flow/{rep}", lambda: fd.main(["seq_to_run.txt", "weights/pwc.pth.tar", f"{inter}/flow"]))
     for name, wf in (("general_proposals", "weights/general.pt"), ("specific_proposals", "weights/specific.pt")):
@@ -45,13 +46,16 @@ for rep in ("cold", "warm"):            # cold = plan building + autotuning incl
         q_eng = qd.engine_from_config(qd.Config("code/ReID_net/configs/run"))
     stage_time(f"refinement/{rep}", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_proposals/"))
     stage_time(f"reid/{rep}", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_proposals/", f"{inter}/ReID_proposals/"))
+if ONLY_STREAM:
+    r_eng = q_eng = None
+    stamps.update({f"{k}/warm": float("nan") for k in ("flow", "general_proposals", "specific_proposals", "refinement")})
 # the optional binary side-car (PREMVOS_SIDECAR=1): refinement writes <frame>.pmv (bit-packed masks), ReID reads it
-stage_time("refinement(side-car)/warm", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_sidecar/", sidecar=True))
-stage_time("reid(side-car)/warm", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_sidecar/", f"{inter}/ReID_sidecar/"))
+if not ONLY_STREAM: stage_time("refinement(side-car)/warm", lambda: rd.forward_directory(r_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/combined_proposals/", f"{inter}/refined_sidecar/", sidecar=True))
+if not ONLY_STREAM: stage_time("reid(side-car)/warm", lambda: qd.forward_directory(q_eng, "data/DAVIS/JPEGImages/480p/", f"{inter}/refined_sidecar/", f"{inter}/ReID_sidecar/"))
 # the optional GPU JPEG decode (PREMVOS_GPU_JPEG=1): the pool only Huffman-decodes, inverse DCT / colour conversion on the GPU
 os.environ["PREMVOS_GPU_JPEG"] = "1"
 os.system(f"rm -rf {root}/{inter}/flow")
-stage_time("flow(gpu-jpeg)/warm", lambda: fd.main(["seq_to_run.txt", "weights/pwc.pth.tar", f"{inter}/flow"]))
+if not ONLY_STREAM: stage_time("flow(gpu-jpeg)/warm", lambda: fd.main(["seq_to_run.txt", "weights/pwc.pth.tar", f"{inter}/flow"]))
 os.environ["PREMVOS_GPU_JPEG"] = "0"
 del r_eng, q_eng                          # (their plans hold tens of GB of activations; the streaming pipeline builds its own)
 import gc; gc.collect(); torch.cuda.empty_cache()
