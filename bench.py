@@ -172,12 +172,14 @@ def roofline(pipe, batch):
     return {"bound": "mfma", "kernel": "the dense-conv step of the three nets on the fp32 MFMA pipe: conv_igemm_f32_kernel (implicit GEMM; "
                                        "incl. its k-slab / tail-split launches + reduce) or, where the plan-time autotuner measured it faster, "
                                        "wino_gemm_kernel + wino_output_kernel or the slab-free wino_fused_kernel (Winograd F(2x2,3x3) for 3x3 "
-                                       "stride-1 layers: 2.25x fewer multiplies, so `achieved` -- ALGORITHMIC 2*M*K*N FLOPs / time -- can exceed what the pipe issues); the "
+                                       "stride-1 layers: 2.25x fewer multiplies) or wino4_input / wino4_gemm / wino4_output (F(4x4,3x3) for K-rich "
+                                       "layers: 4x fewer multiplies), so `achieved` -- ALGORITHMIC 2*M*K*N FLOPs / time -- can exceed what the pipe issues); the "
                                        "seven 1-2 channel heads run on conv_smalln_kernel and are counted with their algorithmic FLOPs",
-            "winograd_layers": sum(1 for it in items if it[5].tile_hint in (2, 3)),
+            "winograd_layers": sum(1 for it in items if it[5].tile_hint in (2, 3, 4)),
+            "winograd_f4x4_layers": sum(1 for it in items if it[5].tile_hint == 4),
             "winograd_slab_free_layers": sum(1 for it in items if it[5].tile_hint == 3),
-            # FLOPs the matrix pipe actually issues (a Winograd layer issues 16/36 of its algorithmic 3x3 FLOPs) / time / peak
-            "mfma_issue_frac": round(sum(it[3] * (16.0 / 36.0 if it[5].tile_hint in (2, 3) else 1.0) for it in items) / (ms * 1e-3) / 1e12
+            # FLOPs the matrix pipe actually issues (an F(2x2,3x3) layer issues 16/36 of its algorithmic 3x3 FLOPs, F(4x4,3x3) 36/144) / time / peak
+            "mfma_issue_frac": round(sum(it[3] * (16.0 / 36.0 if it[5].tile_hint in (2, 3) else 0.25 if it[5].tile_hint == 4 else 1.0) for it in items) / (ms * 1e-3) / 1e12
                                      / PEAK_F32_TFLOPS, 4),
             "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -87,7 +87,8 @@ typedef struct premvos_conv_desc {
   int32_t tile_hint;    /* 0 = auto; (BM<<16)|BN forces an MFMA tile config; 1 forces the direct kernel for cout <= 2;  */
                         /* 2 = Winograd F(2x2,3x3) (csrc/conv_wino_f32.hip; needs wgt_wino), 16 component slabs in the  */
                         /* workspace + an output-transform launch; 3 = the same algebra in ONE kernel without workspace */
-                        /* (a workgroup walks all 16 components of its block; output transform from registers)          */
+                        /* (a workgroup walks all 16 components of its block; output transform from registers);         */
+                        /* 4 = Winograd F(4x4,3x3) (needs wgt_wino4 + workspace): 4x fewer multiplies, for K-rich layers  */
   int32_t split_k;      /* 0 = auto, <0 = never, >0 = force this many k-slices */
   float* workspace;     /* split-K partial slabs (may be NULL: then never split) */
   int64_t workspace_bytes;
@@ -101,6 +102,9 @@ typedef struct premvos_conv_desc {
   const float* wgt_wino; /* optional (3x3 / stride 1 / dilation 1 / fp32 / cout % 4 == 0): the 16 Winograd F(2x2,3x3) filter  */
                          /* transforms U[c] = (G g G^T)[c/4][c%4], each packed [cout_pad][roundup(cin_pad,16)] with k = cin;   */
                          /* used when tile_hint == 2 (needs premvos_conv2d_workspace_bytes() of workspace); NULL = not packed */
+  const float* wgt_wino4; /* optional, same layers: the 36 Winograd F(4x4,3x3) filter transforms U[6i+j] = (G g G^T)[i][j], packed  */
+                          /* like wgt_wino; used when tile_hint == 4 (csrc/conv_wino4_f32.hip: input transform, 36 batched GEMMs,  */
+                          /* output transform around workspace slabs; stage_k == 64: 64 instead of 128 tile rows per workgroup)    */
 } premvos_conv_desc;
 
 int premvos_conv2d_f32(const premvos_conv_desc* d, void* stream);

@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("tile_hint", C.c_int32), ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("precision", C.c_int32), ("stage_k", C.c_int32), ("wgt_lo", C.c_void_p),
         ("tail_m_tiles", C.c_int32), ("tail_split_k", C.c_int32), ("wgt_wino", C.c_void_p),
+        ("wgt_wino4", C.c_void_p),
     ]
 
 

@@ -40,6 +40,14 @@ __device__ inline float4 arbitrary4() {
   return t;
 }
 
+// A 16-byte load whose result is meant to live in a register ARRAY element: `arr[i] = *reinterpret_cast<const float4*>(p)` is an
+// aggregate copy into the array, which hipcc leaves in scratch memory (measured: the staging registers of a GEMM loop went through
+// scratch_store / scratch_load, 75 instead of 115 TFLOP/s); building the value from its components keeps the array in VGPRs.
+__device__ inline float4 ld4(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+
 // The dispatcher places workgroup `id` of a launch on XCD id % 8 (eight XCDs, a private L2 each).  Returns the position of
 // workgroup `id` in an order in which every XCD owns ONE contiguous run of the `nwg` work items: neighbours in the work raster
 // (tiles sharing halos, the N tiles of one row of A) then share an L2.  A bijection on [0, nwg): pure speed, any order is correct.

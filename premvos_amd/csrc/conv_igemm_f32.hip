@@ -363,6 +363,9 @@ long conv_wino_workspace_bytes(const premvos_conv_desc& d);
 int conv_wino(const premvos_conv_desc& d, hipStream_t s);
 int conv_wino_fused(const premvos_conv_desc& d, hipStream_t s);
 bool conv_wino_fused_applicable(const premvos_conv_desc& d);
+bool conv_wino4_applicable(const premvos_conv_desc& d);       // conv_wino4_f32.hip
+long conv_wino4_workspace_bytes(const premvos_conv_desc& d);
+int conv_wino4(const premvos_conv_desc& d, hipStream_t s);
 bool conv_smalln_applicable(const premvos_conv_desc& d);      // conv_smalln_f32.hip
 int conv_smalln(const premvos_conv_desc& d, hipStream_t s);
 int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin) {
@@ -551,6 +554,11 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
                "symmetric padding and packed filter transforms (wgt_wino)");
     return premvos::conv_wino(d, s);
   }
+  if (d.tile_hint == 4) {      // Winograd F(4x4,3x3) for K-rich layers (input transform, 36 batched GEMMs, output transform)
+    PV_REQUIRE(premvos::conv_wino4_applicable(d), "conv2d: Winograd F(4x4,3x3) needs a 3x3 / stride 1 / dilation 1 fp32 layer with "
+               "cout %% 4 == 0, symmetric padding and packed filter transforms (wgt_wino4)");
+    return premvos::conv_wino4(d, s);
+  }
   if (d.tile_hint == 3) {      // ... the slab-free variant of it (no workspace, one kernel); stage_k = block id
     PV_REQUIRE(premvos::conv_wino_fused_applicable(d), "conv2d: Winograd needs a 3x3 / stride 1 fp32 layer with cout %% 4 == 0, symmetric "
                "padding (= the dilation for atrous layers) and packed filter transforms (wgt_wino)");
@@ -589,6 +597,7 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   if (dp->precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16_workspace_bytes(*dp);
   if (dp->tile_hint == 2) return premvos::conv_wino_applicable(*dp) ? premvos::conv_wino_workspace_bytes(*dp) : 0;
   if (dp->tile_hint == 3) return 0;
+  if (dp->tile_hint == 4) return premvos::conv_wino4_applicable(*dp) ? premvos::conv_wino4_workspace_bytes(*dp) : 0;
   if ((dp->tile_hint == 0 || dp->tile_hint == 1) && premvos::conv_smalln_applicable(*dp)) return 0;
   int bm, bn;
   pick_tile(*dp, &bm, &bn);

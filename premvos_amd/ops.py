@@ -69,6 +69,7 @@ class PackedConv:
     precision: int = 0        # _lib.PREC_*; bf16 modes: wgt / wgt_lo are bfloat16 [cout_pad][k_pad], k_pad % 32 == 0
     wgt_lo: Optional[torch.Tensor] = None
     wgt_wino: Optional[torch.Tensor] = None      # fp32 3x3 layers: the 16 Winograd F(2x2,3x3) filter transforms [16][cout_pad][r16(cin_pad)]
+    wgt_wino4: Optional[torch.Tensor] = None     # K-rich fp32 3x3 layers: the 36 F(4x4,3x3) filter transforms, same packing
 
 
 def default_precision() -> str:
@@ -102,6 +103,8 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
         pk = PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
         if (kh, kw) == (3, 3) and cout % 4 == 0 and cin >= WINO_MIN_CIN and wino_enabled():
             pk.wgt_wino = pack_winograd(w, cin_pad, cout_pad, device)
+            if cin >= WINO4_MIN_C and cout >= WINO4_MIN_COUT and wino4_enabled():
+                pk.wgt_wino4 = pack_winograd4(w, cin_pad, cout_pad, device)
         return pk
     hi = full.to(torch.bfloat16)
     lo = (full - hi.float()).to(torch.bfloat16) if prec == _lib.PREC_BF16X3 else None
@@ -115,6 +118,28 @@ WINO_MIN_CIN = 16
 def wino_enabled() -> bool:
     import os
     return os.environ.get("PREMVOS_WINOGRAD", "1") != "0"
+
+
+WINO4_MAX_WS = 4 << 30      # bytes of workspace one layer may ask for
+WINO4_MIN_C, WINO4_MIN_COUT = 128, 64       # F(4x4,3x3) moves 2.25x the input and output through workspace slabs: only K- and N-rich layers gain
+
+
+def wino4_enabled() -> bool:
+    import os
+    return os.environ.get("PREMVOS_WINOGRAD4", "1") != "0"
+
+
+def pack_winograd4(w_oihw: torch.Tensor, cin_pad: int, cout_pad: int, device="cpu") -> torch.Tensor:
+    """U[6*i+j] = (G g G^T)[i][j] of F(4x4,3x3) (Lavin & Gray 2016; points 0, +-1, +-2, inf) for every (cout, cin) filter g, in
+    float64 on ``device`` and rounded once; packed like ``pack_winograd``: [36][cout_pad][roundup(cin_pad, 16)]."""
+    cout, cin = w_oihw.shape[:2]
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                      [0, 0, 1]], dtype=torch.float64, device=device)
+    g = w_oihw.to(device=device, dtype=torch.float64)
+    u = torch.einsum("ia,ocab,jb->ijoc", G, g, G).reshape(36, cout, cin)
+    out = torch.zeros((36, cout_pad, _r(cin_pad, 16)), dtype=torch.float32, device=device)
+    out[:, :cout, :cin] = u.to(torch.float32)
+    return out
 
 
 def pack_winograd(w_oihw: torch.Tensor, cin_pad: int, cout_pad: int, device="cpu") -> torch.Tensor:
@@ -205,6 +230,7 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     d.precision = pk.precision
     d.wgt_lo = pk.wgt_lo.data_ptr() if pk.wgt_lo is not None else None
     d.wgt_wino = pk.wgt_wino.data_ptr() if pk.wgt_wino is not None else None
+    d.wgt_wino4 = pk.wgt_wino4.data_ptr() if pk.wgt_wino4 is not None else None
     return d
 
 
@@ -239,7 +265,7 @@ BUILD_LOCK = __import__("threading").RLock()
 
 def _sig(d: ConvDesc):
     return (d.n, d.h, d.w, d.cin, d.ho, d.wo, d.cout, d.kh, d.kw, d.sh, d.sw, d.dh, d.dw, bool(d.res), d.out_mode,
-            d.precision, d.in_ps, d.out_ps, bool(d.wgt_wino))
+            d.precision, d.in_ps, d.out_ps, bool(d.wgt_wino), bool(d.wgt_wino4))
 
 
 def wino_applicable(d: ConvDesc) -> bool:
@@ -278,6 +304,12 @@ def _candidates(d: ConvDesc):
         # (stage_k = block id, see conv_wino_f32.hip: tile rows x couts / waves / stage depth); it also takes atrous layers
         if os.environ.get("PREMVOS_WINOGRAD_FUSED", "1") != "0":
             out.extend((3, v, -1, 0, 0) for v in (() if d.cout <= 32 else (3, 5) if d.cout <= 64 else (0, 2, 4, 6)))
+    if wino_applicable(d) and bool(d.wgt_wino4) and os.environ.get("PREMVOS_WINOGRAD4", "1") != "0":
+        # tile_hint 4 = Winograd F(4x4,3x3) (csrc/conv_wino4_f32.hip): 4x fewer multiplies, 2.25x the input + output through slabs
+        mt4 = d.n * -(-d.ho // 4) * -(-d.wo // 4)
+        if 36 * mt4 * (_r(d.cin_pad, 16) + _r(d.cout, 128)) * 4 <= WINO4_MAX_WS:
+            out.append((4, 0, -1, 0, 0))
+            out.append((4, 64, -1, 0, 0))
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((256, 128), (128, 128), (128, 64), (64, 128))) else [16]

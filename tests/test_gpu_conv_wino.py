@@ -83,6 +83,41 @@ def test_atrous_winograd_matches_torch(n, cin, cout, h, w, dil):
     assert any(c[0] == 3 for c in ops._candidates(d)) and not any(c[0] == 2 for c in ops._candidates(d))
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,act,res", [(1, 256, 256, 46, 83, "relu", False), (2, 128, 128, 32, 40, "leaky", True),
+                                                    (1, 1024, 1024, 12, 21, "relu", False), (3, 130, 132, 9, 5, "none", True),
+                                                    (5, 512, 512, 7, 7, "relu", True), (1, 160, 136, 4, 3, "relu", False), (2, 245, 64, 20, 36, "leaky", False)])
+def test_winograd_4x4_matches_torch(n, cin, cout, h, w, act, res):
+    """F(4x4,3x3) (csrc/conv_wino4_f32.hip: input transform, 36 batched GEMMs, output transform; tile_hint 4) on K-rich layers:
+    maps that are not multiples of the 4x4 tile, channel counts off the GEMM tiles, channel windows, fused epilogue."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    r = torch.randn((n, cout, h, w), generator=g) if res else None
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+    ref = {"relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t}[act](ref)
+    a = {"relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY, "none": ops.ACT_NONE}[act]
+    pk = ops.pack_conv(wt, b)
+    assert pk.wgt_wino4 is not None and tuple(pk.wgt_wino4.shape) == (36, pk.cout_pad, (pk.cin_pad + 15) // 16 * 16)
+    xin = _nhwc(x, ops, ps=(cin + 3) // 4 * 4 + 8, coff=4)
+    rin = _nhwc(r, ops) if res else None
+    scale = max(1.0, ref.abs().max().item())
+    d = ops.conv_desc(xin, pk, ops.NHWC.alloc(n, h, w, cout), pad=(1, 1))
+    assert any(c[0] == 4 for c in ops._candidates(d))
+    for stage_k, coff, extra in ((0, 4, 8), (64, 0, 0), (0, 2, 3)):            # (0, 2, 3): an unaligned window -> scalar stores
+        out = ops.NHWC.alloc(n, h, w, cout + extra)
+        out.buf.fill_(3.0)
+        ops.conv2d(xin, pk, out.slice(coff, cout), pad=(1, 1), act=a, res=rin, tile_hint=4, stage_k=stage_k)
+        torch.cuda.synchronize()
+        assert torch.all(out.buf[..., :coff] == 3.0) and torch.all(out.buf[..., coff + cout:] == 3.0)      # window respected
+        got = out.slice(coff, cout).torch().cpu().double()
+        # the transforms scale by up to 100 / down to 1/576 before the products: ~1e-5 of the output scale (F(2x2,3x3): ~1e-6)
+        assert (got - ref).abs().max().item() < 2e-4 * scale, (stage_k, coff)
+
+
 def test_winograd_is_refused_where_it_does_not_apply():
     from premvos_amd import _lib
     ops = _ops()
@@ -93,6 +128,10 @@ def test_winograd_is_refused_where_it_does_not_apply():
         ops.conv2d(x, pk, out, stride=(2, 2), pad=(1, 1), tile_hint=2)          # stride 2
     with pytest.raises(_lib.PremvosError, match="Winograd"):
         ops.conv2d(x, pk, out, stride=(2, 2), pad=(1, 1), tile_hint=3)
+    out8 = ops.NHWC.alloc(1, 8, 8, 16)
+    assert pk.wgt_wino4 is None                   # 16 channels: F(4x4,3x3) is only packed for K- and N-rich layers
+    with pytest.raises(_lib.PremvosError, match="4x4"):
+        ops.conv2d(x, pk, out8, pad=(1, 1), tile_hint=4)
     out1 = ops.NHWC.alloc(1, 8, 8, 16)
     with pytest.raises(_lib.PremvosError, match="block id"):
         ops.conv2d(x, pk, out1, pad=(1, 1), tile_hint=3, stage_k=11)

@@ -20,7 +20,7 @@ for _ in range(5):
     for i, (a, b) in enumerate(evs): samples[i].append(a.elapsed_time(b))
 rows = []
 for (st, name, fn, fl, _, d), sm in zip(items, samples):
-    name = name + (" [winograd]" if d.tile_hint == 2 else f" [winograd, slab-free {d.stage_k}]" if d.tile_hint == 3 else "")
+    name = name + (" [winograd]" if d.tile_hint == 2 else f" [winograd, slab-free {d.stage_k}]" if d.tile_hint == 3 else " [winograd F(4x4)]" if d.tile_hint == 4 else "")
     ms = sorted(sm)[2]; mult = pipe.refine_calls_per_step if st == "refine" else 1
     per = fl / mult
     rows.append((ms * mult - fl / 120e9, st, name, ms, per / ms / 1e9, mult))

@@ -9,8 +9,8 @@ import csv
 import json
 import sys
 
-KERNELS = ("conv_igemm_f32_kernel", "wino_gemm_kernel", "wino_output_kernel", "wino_fused_kernel", "splitk_reduce_kernel",
-           "conv_smalln_kernel")
+KERNELS = ("conv_igemm_f32_kernel", "wino_gemm_kernel", "wino_output_kernel", "wino_fused_kernel", "wino4_input_kernel",
+           "wino4_gemm_kernel", "wino4_output_kernel", "splitk_reduce_kernel", "conv_smalln_kernel")
 
 
 def total(path, counter):

@@ -30,7 +30,7 @@ for name, n, cin, cout, h, w in LAYERS:
     pk = ops.pack_conv(torch.randn((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5, torch.zeros(cout))
     flops = 2.0 * n * h * w * 9 * cin * cout
     d = ops.conv_desc(x, pk, out, pad=(1, 1), act=ops.ACT_RELU)
-    best, tw, tf = (1e30, None), (1e30, None), {}
+    best, tw, tf, t4 = (1e30, None), (1e30, None), {}, {}
     for cand in ops._candidates(d):
         d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = cand
         ws = ops.assign_workspace([d])
@@ -39,9 +39,13 @@ for name, n, cin, cout, h, w in LAYERS:
             tw = min(tw, (t, cand[1]))
         elif cand[0] == 3:
             tf[cand[1]] = t
+        elif cand[0] == 4:
+            t4[cand[1]] = t
         elif t < best[0]:
             best = (t, cand)
     fused = " ".join(f"[{v}] {t:8.1f}" for v, t in sorted(tf.items()))
     tfb = min(tf.values()) if tf else float("nan")
     print(f"{name:34s} gemm {best[0]:9.1f} us {flops / best[0] / 1e6:6.1f} TF/s | slabs {tw[0]:9.1f} us (bm {tw[1] or 128}) {flops / tw[0] / 1e6:6.1f} | "
-          f"fused {fused} us -> {flops / tfb / 1e6:6.1f} TF/s-equiv  x{tw[0] / tfb:.2f} vs slabs", flush=True)
+          f"fused {fused} us -> {flops / tfb / 1e6:6.1f} TF/s-equiv  x{tw[0] / tfb:.2f} vs slabs"
+          + (" | F(4x4) " + " ".join(f"[{v or 128}] {t:8.1f}" for v, t in sorted(t4.items())) + f" us -> {flops / min(t4.values()) / 1e6:6.1f} TF/s-equiv"
+             f"  x{min(best[0], tw[0], tfb) / min(t4.values()):.2f} vs the best other" if t4 else ""), flush=True)
