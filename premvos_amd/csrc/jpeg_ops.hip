@@ -57,8 +57,18 @@ struct BitReader {
   bool hit_marker = false;
   int fed = 0;                                    // zero bytes fed behind the end of the segment
   bool overran() const { return n < 8 * fed; }    // some of them were consumed: the data ended early
-  void fill() {                                   // keep >= 32 bits; a marker feeds zeros (the segment has ended)
+  void fill() {                                   // top the accumulator up (>= 57 bits, or zeros behind the end of the segment)
     while (n <= 56) {
+      if (n <= 32 && !hit_marker && p + 4 <= end) {               // four stuffing-free bytes at once (the common case)
+        const uint32_t w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+        const uint32_t inv = ~w;
+        if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {   // no 0xFF byte among them
+          acc |= (uint64_t)w << (32 - n);
+          n += 32;
+          p += 4;
+          continue;
+        }
+      }
       uint32_t b = 0;
       if (!hit_marker && p < end) {
         b = *p;
@@ -97,8 +107,9 @@ struct BitReader {
   }
 };
 
+// Both helpers expect the caller to have topped the reader up to >= 32 bits: a Huffman code (<= 16 bits) followed by its value
+// bits (<= 15) never needs more.
 inline int decode_symbol(BitReader& br, const Huff& h) {
-  if (br.n < 16) br.fill();
   const uint16_t f = h.fast[br.peek(9)];
   if (f) {
     br.skip(f >> 8);
@@ -115,7 +126,6 @@ inline int decode_symbol(BitReader& br, const Huff& h) {
 }
 
 inline int receive_extend(BitReader& br, int t) {   // T.81 F.2.2.1
-  if (br.n < t) br.fill();
   const int v = (int)br.peek(t);
   br.skip(t);
   return v >= (1 << (t - 1)) ? v : v - (1 << t) + 1;
@@ -250,11 +260,13 @@ int parse_header(const uint8_t* d, int64_t n, Parsed& ps) {
 }
 
 inline bool decode_block(BitReader& br, const Huff& dc, const Huff& ac, int& pred, int16_t* blk) {
+  if (br.n < 32) br.fill();
   int t = decode_symbol(br, dc);
   if (t < 0 || t > 11) return false;
   if (t) pred += receive_extend(br, t);
   blk[0] = (int16_t)pred;
   for (int k = 1; k < 64;) {
+    if (br.n < 32) br.fill();
     const int rs = decode_symbol(br, ac);
     if (rs < 0) return false;
     const int r = rs >> 4, s = rs & 15;
