@@ -120,7 +120,7 @@ def wino_enabled() -> bool:
     return os.environ.get("PREMVOS_WINOGRAD", "1") != "0"
 
 
-WINO4_MAX_WS = 4 << 30      # bytes of workspace one layer may ask for
+WINO4_MAX_WS = 16 << 30     # bytes of workspace one layer may ask for
 WINO4_MIN_C, WINO4_MIN_COUT = 128, 64       # F(4x4,3x3) moves 2.25x the input and output through workspace slabs: only K- and N-rich layers gain
 
 
