@@ -104,7 +104,8 @@ typedef struct premvos_conv_desc {
                          /* used when tile_hint == 2 (needs premvos_conv2d_workspace_bytes() of workspace); NULL = not packed */
   const float* wgt_wino4; /* optional, same layers: the 36 Winograd F(4x4,3x3) filter transforms U[6i+j] = (G g G^T)[i][j], packed  */
                           /* like wgt_wino; used when tile_hint == 4 (csrc/conv_wino4_f32.hip: input transform, 36 batched GEMMs,  */
-                          /* output transform around workspace slabs; stage_k == 64: 64 instead of 128 tile rows per workgroup)    */
+                          /* output transform around workspace slabs; stage_k = GEMM block: +64 = 64 instead of 128 tile rows per  */
+                          /* workgroup, +16 = 16- instead of 32-deep stages)                                                        */
 } premvos_conv_desc;
 
 int premvos_conv2d_f32(const premvos_conv_desc* d, void* stream);

@@ -323,12 +323,13 @@ long conv_wino4_workspace_bytes(const premvos_conv_desc& d) {
   return 36L * g.mt * ((long)g.kp + (long)g.n_tiles * g.bn) * (long)sizeof(float);
 }
 
-// tile_hint 4; stage_k == 64 selects 64-tile-row workgroups (twice as many, half as long)
+// tile_hint 4; stage_k picks the GEMM block: 0 / 64 / 16 / 80
 int conv_wino4(const premvos_conv_desc& d, hipStream_t s) {
   const Geo g = geometry(d);
   if (d.workspace == nullptr || d.workspace_bytes < conv_wino4_workspace_bytes(d))
     return fail(PREMVOS_EINVAL, "conv2d(winograd 4x4): needs %ld workspace bytes", conv_wino4_workspace_bytes(d));
   if (g.mt >= (1L << 26)) return fail(PREMVOS_EINVAL, "conv2d(winograd 4x4): too many tiles");
+  if (d.stage_k & ~(64 | 16)) return fail(PREMVOS_EINVAL, "conv2d(winograd 4x4): stage_k %d is not a block id (0, 16, 64, 80)", d.stage_k);
   float* V = d.workspace;
   float* Ms = d.workspace + 36L * g.mt * g.kp;
   {
@@ -338,7 +339,9 @@ int conv_wino4(const premvos_conv_desc& d, hipStream_t s) {
     const int rc = check_launch("wino4_input");
     if (rc) return rc;
   }
-  const bool bm64 = d.stage_k == 64, k32 = g.kp % 32 == 0;
+  // stage_k: bit 6 (64) = 64 instead of 128 tile rows per workgroup, bit 4 (16) = 16- instead of 32-deep stages (three
+  // instead of two workgroups per CU: the better trade for short K, where a tile's first loads and epilogue weigh most)
+  const bool bm64 = (d.stage_k & 64) != 0, k32 = g.kp % 32 == 0 && (d.stage_k & 16) == 0;
   int rc;
   if (g.bn == 64) {
     rc = bm64 ? (k32 ? launch_gemm<64, 64, 2, 2, 32>(d, g, V, Ms, s) : launch_gemm<64, 64, 2, 2, 16>(d, g, V, Ms, s))

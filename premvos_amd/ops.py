@@ -308,8 +308,7 @@ def _candidates(d: ConvDesc):
         # tile_hint 4 = Winograd F(4x4,3x3) (csrc/conv_wino4_f32.hip): 4x fewer multiplies, 2.25x the input + output through slabs
         mt4 = d.n * -(-d.ho // 4) * -(-d.wo // 4)
         if 36 * mt4 * (_r(d.cin_pad, 16) + _r(d.cout, 128)) * 4 <= WINO4_MAX_WS:
-            out.append((4, 0, -1, 0, 0))
-            out.append((4, 64, -1, 0, 0))
+            out.extend((4, v, -1, 0, 0) for v in (0, 64, 16, 80))     # GEMM block: 128 / 64 tile rows x 32- / 16-deep stages
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((256, 128), (128, 128), (128, 64), (64, 128))) else [16]

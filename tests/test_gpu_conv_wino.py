@@ -107,7 +107,7 @@ def test_winograd_4x4_matches_torch(n, cin, cout, h, w, act, res):
     scale = max(1.0, ref.abs().max().item())
     d = ops.conv_desc(xin, pk, ops.NHWC.alloc(n, h, w, cout), pad=(1, 1))
     assert any(c[0] == 4 for c in ops._candidates(d))
-    for stage_k, coff, extra in ((0, 4, 8), (64, 0, 0), (0, 2, 3)):            # (0, 2, 3): an unaligned window -> scalar stores
+    for stage_k, coff, extra in ((0, 4, 8), (64, 0, 0), (16, 0, 4), (80, 4, 4), (0, 2, 3)):      # (0, 2, 3): an unaligned window -> scalar stores
         out = ops.NHWC.alloc(n, h, w, cout + extra)
         out.buf.fill_(3.0)
         ops.conv2d(xin, pk, out.slice(coff, cout), pad=(1, 1), act=a, res=rin, tile_hint=4, stage_k=stage_k)
@@ -132,6 +132,10 @@ def test_winograd_is_refused_where_it_does_not_apply():
     assert pk.wgt_wino4 is None                   # 16 channels: F(4x4,3x3) is only packed for K- and N-rich layers
     with pytest.raises(_lib.PremvosError, match="4x4"):
         ops.conv2d(x, pk, out8, pad=(1, 1), tile_hint=4)
+    x2 = ops.NHWC.alloc(1, 8, 8, 128)
+    pk2 = ops.pack_conv(torch.randn((128, 128, 3, 3)) * 0.03, None)
+    with pytest.raises(_lib.PremvosError, match="block id"):
+        ops.conv2d(x2, pk2, ops.NHWC.alloc(1, 8, 8, 128), pad=(1, 1), tile_hint=4, stage_k=32)
     out1 = ops.NHWC.alloc(1, 8, 8, 16)
     with pytest.raises(_lib.PremvosError, match="block id"):
         ops.conv2d(x, pk, out1, pad=(1, 1), tile_hint=3, stage_k=11)
