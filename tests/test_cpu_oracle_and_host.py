@@ -187,3 +187,38 @@ def test_product_path_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
                     bad.append(os.path.join(dirpath, fn))
     assert not bad, bad
+
+
+def test_winograd_filter_transforms_reproduce_the_convolution():
+    """Host logic of the two Winograd paths (ops.pack_winograd: F(2x2,3x3), ops.pack_winograd4: F(4x4,3x3)): the packed filter
+    transforms U = G g G^T, multiplied with B^T d B and folded with A^T . A in float64, give the direct 3x3 convolution (the
+    matrices the kernels of csrc/conv_wino_f32.hip / conv_wino4_f32.hip implement)."""
+    from premvos_amd import ops
+    g = torch.Generator().manual_seed(3)
+    cin, cout, h, w = 20, 12, 9, 7
+    x = torch.randn((1, cin, h, w), generator=g, dtype=torch.float64)
+    wt = torch.randn((cout, cin, 3, 3), generator=g, dtype=torch.float64) * 0.1
+    ref = torch.nn.functional.conv2d(x, wt, padding=1)
+    variants = {
+        2: (ops.pack_winograd, torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64),
+            torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)),
+        4: (ops.pack_winograd4, torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                                              [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64),
+            torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)),
+    }
+    for m, (pack, BT, AT) in variants.items():
+        t = m + 2
+        packed = pack(wt.float(), 20, 32, "cpu")
+        assert tuple(packed.shape) == (t * t, 32, 32) and packed.dtype == torch.float32
+        assert packed[:, cout:].abs().max() == 0 and packed[:, :, cin:].abs().max() == 0       # zero padded
+        U = packed.double()[:, :cout, :cin].reshape(t, t, cout, cin)
+        ty, tx = -(-h // m), -(-w // m)
+        xp = torch.nn.functional.pad(x, (1, m * tx + 1 - w, 1, m * ty + 1 - h))
+        out = torch.zeros((cout, m * ty, m * tx), dtype=torch.float64)
+        for a in range(ty):
+            for b in range(tx):
+                d = xp[0, :, m * a:m * a + t, m * b:m * b + t]
+                V = torch.einsum("ia,cab,jb->ijc", BT, d, BT)
+                M = torch.einsum("ijc,ijoc->ijo", V, U)
+                out[:, m * a:m * a + m, m * b:m * b + m] = torch.einsum("ai,ijo,bj->oab", AT, M, AT)
+        assert (out[:, :h, :w] - ref[0]).abs().max().item() < 1e-5, m         # (fp32 rounding of the packed filters)
