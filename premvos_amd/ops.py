@@ -131,14 +131,18 @@ def wino4_enabled() -> bool:
 
 def pack_winograd4(w_oihw: torch.Tensor, cin_pad: int, cout_pad: int, device="cpu") -> torch.Tensor:
     """U[6*i+j] = (G g G^T)[i][j] of F(4x4,3x3) (Lavin & Gray 2016; points 0, +-1, +-2, inf) for every (cout, cin) filter g, in
-    float64 on ``device`` and rounded once; packed like ``pack_winograd``: [36][cout_pad][roundup(cin_pad, 16)]."""
+    float64 on ``device`` and rounded once; packed like ``pack_winograd``: [36][cout_pad][roundup(cin_pad, 16)].
+    G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]] written out as element-wise float64
+    sums (IEEE: the same bits on host and GPU, and no BLAS call at model set-up)."""
     cout, cin = w_oihw.shape[:2]
-    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                      [0, 0, 1]], dtype=torch.float64, device=device)
     g = w_oihw.to(device=device, dtype=torch.float64)
-    u = torch.einsum("ia,ocab,jb->ijoc", G, g, G).reshape(36, cout, cin)
+
+    def G(a, b, c):                                  # the six rows of G applied to three values
+        return (a / 4, -(a + b + c) / 6, -(a - b + c) / 6, (a + 2 * b + 4 * c) / 24, (a - 2 * b + 4 * c) / 24, c)
     out = torch.zeros((36, cout_pad, _r(cin_pad, 16)), dtype=torch.float32, device=device)
-    out[:, :cout, :cin] = u.to(torch.float32)
+    for i, r in enumerate(G(g[:, :, 0], g[:, :, 1], g[:, :, 2])):             # filter rows -> [cout, cin, 3]
+        for j, col in enumerate(G(r[..., 0], r[..., 1], r[..., 2])):
+            out[6 * i + j, :cout, :cin] = col.to(torch.float32)
     return out
 
 
