@@ -143,3 +143,22 @@ def test_loader_is_the_default_reader_unless_enabled(monkeypatch):
     assert jpeg.loader() is jpeg._pil_rgb
     monkeypatch.setenv("PREMVOS_GPU_JPEG", "1")
     assert jpeg.loader() is jpeg.host_stage
+
+
+def test_frame_helpers_on_host_arrays_and_tensors():
+    """``stack_frames`` / ``to_device`` (what every driver calls at its upload site) with the default reader's arrays: one [n,H,W,3]
+    uint8 tensor, RGB kept or flipped to the cv2.imread order; an RGBA array loses its alpha plane; a tensor passes through."""
+    import torch
+    from premvos_amd import jpeg
+    a, b = picture(6, 9, seed=1), picture(6, 9, seed=2)
+    st = jpeg.stack_frames([a, b], "cpu")
+    assert st.dtype == torch.uint8 and tuple(st.shape) == (2, 6, 9, 3)
+    assert np.array_equal(st[0].numpy(), a) and np.array_equal(st[1].numpy(), b)
+    assert np.array_equal(jpeg.stack_frames([a, b], "cpu", bgr=True)[1].numpy(), b[:, :, ::-1])
+    rgba = np.concatenate([a, np.full((6, 9, 1), 255, np.uint8)], axis=2)
+    assert np.array_equal(jpeg.to_device(rgba, "cpu").numpy(), a)
+    t = torch.from_numpy(a.copy())
+    assert jpeg.to_device(t, "cpu") is t
+    assert np.array_equal(jpeg.to_device(t, "cpu", bgr=True).numpy(), a[:, :, ::-1])
+    mixed = jpeg.stack_frames([a, torch.from_numpy(b.copy())], "cpu")
+    assert np.array_equal(mixed[1].numpy(), b)
