@@ -52,6 +52,13 @@ def parse():
                     help="MFMA arithmetic of the dense convs; mixed-*: PWC-Net fp32, proposal/refinement in the bf16 mode")
     ap.add_argument("--frame", default="480p", choices=["480p", "1080p"],
                     help="480p = the metric's DAVIS shape (default); 1080p = configs[4]'s 1080x1920 frames (supplementary)")
+    ap.add_argument("--scaling", default=os.environ.get("PREMVOS_BENCH_SCALING", "strong"), choices=["strong", "weak"],
+                    help="strong (default): ONE synthetic video of --frames frames is shared out over the ranks exactly as the product "
+                         "shards a video (premvos_amd.parallel.plan_shards: chunk-aligned contiguous ranges, boundary frame read as the "
+                         "second image of a rank's last pair, ragged last chunk); a step = one pass over the video.  weak: every rank "
+                         "owns --batch frames per step (rounds 1-2)")
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("PREMVOS_BENCH_FRAMES", "0")),
+                    help="strong scaling: frame pairs of the video (default 16 chunks = 16 x --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -271,29 +278,71 @@ def main():
     pipe = FramePipeline(synth.pwc_state_dict(0), synth.proposal_weights(0), synth.proposal_weights(1),
                          synth.refinement_weights(0), batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec,
                          flow_precision=flow_prec)
-    fa, fb = synth_frames(B, rank)
-    fa, fb = fa.to(dev), fb.to(dev)
-    boxes = synth_boxes(B, rank).to(dev)
+    strong = a.scaling == "strong"
+    T = (a.frames if a.frames > 0 else 16 * B) if strong else B * world
     xchg = ResultExchange(B, H, W, P_BOXES, dev) if use_dist else None
+    if strong:
+        # the product's own sharding of ONE video (premvos_amd.stream.run): chunk-aligned frame ranges; frame pair t = (t, t+1)
+        # belongs to the owner of frame t, so a rank also reads frame `end` (the video has T + 1 frames: T pairs)
+        from premvos_amd.parallel import plan_shards
+        plans = [plan_shards([T], world, r, B) for r in range(world)]
+        mine = plans[rank]
+        chunks = []                                     # (frames_a, frames_b, boxes, valid frames) resident in HBM
+        for _, s0, e0 in mine:
+            clip = synth.clip_frames(s0, e0 + 1, H, W).to(dev)
+            cb = synth.clip_boxes(s0, e0, P_BOXES, H, W).to(dev)
+            for c0 in range(0, e0 - s0, B):
+                n = min(B, e0 - s0 - c0)
+                ca, cbx, cbb = clip[c0:c0 + n], cb[c0:c0 + n], clip[c0 + 1:c0 + n + 1]
+                if n < B:                               # ragged last chunk of the video: padded to the launch batch (its work is
+                    pad = B - n                         # timed, its frames are not counted)
+                    ca = torch.cat([ca, ca[-1:].expand(pad, -1, -1, -1)]).contiguous()
+                    cbb = torch.cat([cbb, cbb[-1:].expand(pad, -1, -1, -1)]).contiguous()
+                    cbx = torch.cat([cbx, cbx[-1:].expand(pad, -1, -1)]).contiguous()
+                chunks.append((ca.contiguous(), cbb.contiguous(), cbx.contiguous(), n))
+        rounds = max(sum(-(-(e0 - s0) // B) for _, s0, e0 in p) for p in plans)     # exchanges per pass (ranks stay in step)
+        if not chunks:                                  # more ranks than chunks: this rank only takes part in the gathers
+            z = synth.clip_frames(0, 2, H, W).to(dev)
+            chunks_dummy = (z[:1].expand(B, -1, -1, -1).contiguous(), z[1:].expand(B, -1, -1, -1).contiguous(),
+                            synth.clip_boxes(0, 1, P_BOXES, H, W).expand(B, -1, -1).contiguous().to(dev), 0)
+        fa, fb, boxes = (chunks[0] if chunks else chunks_dummy)[:3]
+        last = {"r": None}
 
-    def step():
-        r = pipe.step(fa, fb, boxes)
-        if use_dist:        # the single exchange of the path: ONE gather of one packed buffer -> merge rank
-            xchg.exchange(r)
-        return r
+        def step():                                     # one pass over the video: this rank's chunks + one gather per round
+            for k in range(rounds):
+                if k < len(chunks):
+                    last["r"] = pipe.step(*chunks[k][:3])
+                if use_dist:                            # async: the gather of round k overlaps the compute of round k + 1
+                    xchg.exchange_async(last["r"])
+            return last["r"]
+    else:
+        fa, fb = synth_frames(B, rank)
+        fa, fb = fa.to(dev), fb.to(dev)
+        boxes = synth_boxes(B, rank).to(dev)
+
+        def step():
+            r = pipe.step(fa, fb, boxes)
+            if use_dist:        # the single exchange of the path: ONE gather of one packed buffer -> merge rank
+                xchg.exchange_async(r)
+            return r
 
     if world > 1 and rank == 0:
         pipe.step(fa, fb, boxes)          # builds + tunes every plan (no collective: the other ranks wait in publish())
         torch.cuda.synchronize()
     publish()
+    if strong and not chunks:
+        last["r"] = pipe.step(fa, fb, boxes)            # something to pack for the gathers this rank only takes part in
     for _ in range(a.warmup):
         step()
     if use_dist:
+        xchg.flush()
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    if use_dist:
+        xchg.flush()                      # every gather has landed on the merge rank inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -304,12 +353,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    frames = a.steps * B * world
+    frames = a.steps * T
     out = {
         "metric": "frames/sec (proposal+refine+flow) on 480p DAVIS frames",
         "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": a.scaling, "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (split-fp32 on the bf16 MFMA pipe, f32 accumulate)",
                   "mixed-bf16x3": "flow f32; proposal+refinement bf16x3 (split-fp32, f32 accumulate)",
                   "mixed-bf16": "flow f32; proposal+refinement bf16 (f32 accumulate)"}[prec],
@@ -321,10 +370,15 @@ def main():
                                 "PWC-Net flow (1088x1920) + proposal_net x2 weight sets (750x1333, ResNet-101-C4, 100 RoIs) ")
                                + f"+ refinement_net (Xception-65 DeepLabv3+, {P_BOXES} seeded boxes/frame @385x385); conv arithmetic: {prec}; "
                                + "results (flow, masks, conf, boxes) left in HBM",
-                   "frames_per_step_per_gpu": B, "stages": ["flow", "proposal_general", "proposal_specific", "refinement"],
+                   "frames_per_step": T, "frames_per_launch_per_gpu": B,
+                   "step": (f"one pass over ONE synthetic video of {T} frame pairs = {-(-T // B)} chunks of {B} frames, chunk ranges "
+                            f"shared out over the ranks by premvos_amd.parallel.plan_shards (rank r also reads the first frame of "
+                            f"rank r+1's range; a ragged last chunk is padded to {B} and only its real frames are counted)"
+                            if strong else f"every rank runs its own {B} frames"),
+                   "stages": ["flow", "proposal_general", "proposal_specific", "refinement"],
                    "gflop_per_frame": 2420 if a.frame == "480p" else 3018,
-                   "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; ONE "
-                                  f"{'RCCL' if backend == 'nccl' else backend} gather per step of one packed buffer per rank "
+                   "parallelism": f"frames sharded over {world} GPU(s), no data-path collective; ONE asynchronous "
+                                  f"{'RCCL' if backend == 'nccl' else backend} gather per chunk of one packed buffer per rank "
                                   f"({xchg.nbytes if xchg else 0} B: flow f32, masks bit-packed, boxes/scores/conf) to rank 0"},
     }
     if rank == 0:
@@ -341,6 +395,8 @@ def main():
                                        "source": "profiles/" + os.path.basename(ftf[-1]) + " (tools/time_drivers.py; not measured by this run)"}
             except Exception:
                 pass
+        from premvos_amd import ops
+        out["conv_configurations"] = ops.tune_info()     # which table / rule froze the kernels (reproducibility)
         if not a.no_roofline:
             out["roofline"] = roofline(pipe, B)
         if world == 1 and not a.no_cpu_baseline:

@@ -20,8 +20,11 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+constexpr int64_t kMaxPixels = 64LL << 20;
+
 struct Huff {
   bool present = false;
+  int nsyms = 0;
   uint8_t syms[256];
   int32_t maxcode[18];       // largest code of each length (-1: none), T.81 F.2.2.3
   int32_t valptr[17];        // index of the first symbol of each length
@@ -29,11 +32,21 @@ struct Huff {
   uint16_t fast[512];        // 9-bit prefix -> (length << 8) | symbol, 0 = longer code
 };
 
-void build_huff(Huff& h, const uint8_t* counts, const uint8_t* syms, int n) {
+// false: the code-length counts do not describe a prefix code (over-subscribed: more codes of some length than the code
+// space has left -- libjpeg's jdhuff.c rejects the same tables with JERR_BAD_HUFF_TABLE).  Without the check `code` outgrows
+// 1 << len and the fast-table fill below writes past its 512 entries.
+bool build_huff(Huff& h, const uint8_t* counts, const uint8_t* syms, int n) {
+  int code = 0;
+  for (int len = 1; len <= 16; ++len) {
+    if (code + counts[len - 1] > (1 << len)) return false;
+    code = (code + counts[len - 1]) << 1;
+  }
   h.present = true;
+  h.nsyms = n;
   memcpy(h.syms, syms, n);
   memset(h.fast, 0, sizeof(h.fast));
-  int code = 0, k = 0;
+  code = 0;
+  int k = 0;
   for (int len = 1; len <= 16; ++len) {
     h.valptr[len] = k;
     h.mincode[len] = code;
@@ -47,6 +60,7 @@ void build_huff(Huff& h, const uint8_t* counts, const uint8_t* syms, int n) {
     code <<= 1;
   }
   h.maxcode[17] = 0x7fffffff;
+  return true;
 }
 
 struct BitReader {
@@ -122,7 +136,8 @@ inline int decode_symbol(BitReader& br, const Huff& h) {
   }
   if (len > 16) return -1;
   br.skip(len);
-  return h.syms[h.valptr[len] + code - h.mincode[len]];
+  const int idx = h.valptr[len] + code - h.mincode[len];
+  return (unsigned)idx < (unsigned)h.nsyms ? h.syms[idx] : -1;     // (a bit pattern below the first code of its length)
 }
 
 inline int receive_extend(BitReader& br, int t) {   // T.81 F.2.2.1
@@ -185,7 +200,8 @@ int parse_header(const uint8_t* d, int64_t n, Parsed& ps) {
         int cnt = 0;
         for (int k = 0; k < 16; ++k) cnt += seg[i + 1 + k];
         PV_REQUIRE(tc < 2 && th < 4 && cnt <= 256 && i + 17 + cnt <= sl, "jpeg: bad DHT segment");
-        build_huff(ps.huff[tc][th], seg + i + 1, seg + i + 17, cnt);
+        PV_REQUIRE(build_huff(ps.huff[tc][th], seg + i + 1, seg + i + 17, cnt),
+                   "jpeg: DHT code lengths do not form a prefix code (over-subscribed table)");
         i += 17 + cnt;
       }
     } else if (m == 0xC0 || m == 0xC1) {
@@ -195,6 +211,9 @@ int parse_header(const uint8_t* d, int64_t n, Parsed& ps) {
       I.width = be16(seg + 3);
       ncomp = seg[5];
       PV_REQUIRE(I.height > 0 && I.width > 0, "jpeg: empty frame");
+      // a header may claim 65535 x 65535 pixels (8 GB of pinned coefficients) in front of no data at all: bound what a caller
+      // will be asked to allocate (64 Mpixel = 8192 x 8192; the frames of this pipeline are 0.4 ... 2 Mpixel)
+      PV_REQUIRE((int64_t)I.height * I.width <= kMaxPixels, "jpeg: frame larger than 64 Mpixel");
       if (ncomp != 1 && ncomp != 3) return premvos::fail(PREMVOS_EUNSUPPORTED, "jpeg: %d components", ncomp);
       PV_REQUIRE(sl >= 6 + 3 * ncomp, "jpeg: bad SOF segment");
       for (int c = 0; c < ncomp; ++c) {

@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restr
 #pragma unroll
       for (int cx = 0; cx < NCOL; ++cx) {
         const bool ok = (unsigned)(ix0 + cx) < (unsigned)w;
-        const float lo = PRE_RELU ? 0.f : -INFINITY;
         const float4 t = raw[j][cx];
-        v[cx] = make_float4(ok ? fmaxf(t.x, lo) : 0.f, ok ? fmaxf(t.y, lo) : 0.f, ok ? fmaxf(t.z, lo) : 0.f, ok ? fmaxf(t.w, lo) : 0.f);
+        if constexpr (PRE_RELU)
+          v[cx] = make_float4(ok ? fmaxf(t.x, 0.f) : 0.f, ok ? fmaxf(t.y, 0.f) : 0.f, ok ? fmaxf(t.z, 0.f) : 0.f, ok ? fmaxf(t.w, 0.f) : 0.f);
+        else                                  // no max(x, -inf) identity here: fmaxf(NaN, -inf) = -inf would hide a NaN activation
+          v[cx] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
       }
 #pragma unroll
       for (int o = 0; o < TW; ++o)
@@ -264,8 +266,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
       for (int cx = 0; cx < NCOL; ++cx) {
         const bool ok = row_ok(j) && col_ok(cx);
         const float4& t = vbuf[j & 1][cx];                    // (read only where ok: the conditional below)
-        const float lo = PRE_RELU ? 0.f : -INFINITY;          // max(x, -inf) == x: one instruction either way
-        v[cx] = make_float4(ok ? fmaxf(t.x, lo) : 0.f, ok ? fmaxf(t.y, lo) : 0.f, ok ? fmaxf(t.z, lo) : 0.f, ok ? fmaxf(t.w, lo) : 0.f);
+        if constexpr (PRE_RELU)
+          v[cx] = make_float4(ok ? fmaxf(t.x, 0.f) : 0.f, ok ? fmaxf(t.y, 0.f) : 0.f, ok ? fmaxf(t.z, 0.f) : 0.f, ok ? fmaxf(t.w, 0.f) : 0.f);
+        else                                                  // (NaN / Inf activations propagate unchanged, as in the reference)
+          v[cx] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
       }
 #pragma unroll
       for (int o = 0; o < TR; ++o) {

@@ -28,16 +28,20 @@ from .pwcnet import PWCDCNet, pwc_dc_net
 TAG_FLOAT = 202021.25
 
 
-def writeFlowFile(filename: str, uv: np.ndarray) -> None:
-    """Middlebury .flo writer (script_pwc_multi.py:16-31)."""
+def flo_bytes(uv: np.ndarray) -> bytes:
+    """The bytes of a Middlebury .flo file: tag 202021.25f, int32 W, int32 H, H*W*2 float32 (script_pwc_multi.py:16-31)."""
     uv = np.ascontiguousarray(uv, dtype=np.float32)
     if uv.ndim != 3 or uv.shape[2] != 2:
         raise ValueError("writeFlowFile: flow must have two bands!")
+    return (np.array(TAG_FLOAT, dtype=np.float32).tobytes() + np.array(uv.shape[1], dtype=np.int32).tobytes()
+            + np.array(uv.shape[0], dtype=np.int32).tobytes() + uv.tobytes())
+
+
+def writeFlowFile(filename: str, uv: np.ndarray) -> None:
+    """Middlebury .flo writer (script_pwc_multi.py:16-31)."""
+    data = flo_bytes(uv)
     with open(filename, "wb") as f:
-        f.write(np.array(TAG_FLOAT, dtype=np.float32).tobytes())
-        f.write(np.array(uv.shape[1], dtype=np.int32).tobytes())
-        f.write(np.array(uv.shape[0], dtype=np.int32).tobytes())
-        f.write(uv.tobytes())
+        f.write(data)
 
 
 def readFlowFile(filename: str) -> np.ndarray:
@@ -165,6 +169,9 @@ def main(argv: Optional[List[str]] = None) -> int:
     out = argv[2] if len(argv) > 2 else "output/intermediate/flow"
     with open(name) as f:
         folders = [ln.rstrip() for ln in f if ln.rstrip()]
+    from .. import parallel
+    parallel.bind_device()                      # under torch.distributed.run: one rank per GPU, rank r takes the r-th slice of
+    folders = parallel.my_videos(folders)       # the video list (the reference's curr_run_num / total_to_run scheme)
     t = time()
     net = pwc_dc_net(pwc_model_fn).cuda().eval()
     batch = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "1")))      # pairs per launch list; the host (JPEG decode, .flo
@@ -173,49 +180,57 @@ def main(argv: Optional[List[str]] = None) -> int:
     print("Model setup, in", time() - t, "seconds")
     from .. import io_pipeline as iop
     writer = iop.Writer(enabled=iop.io_threads() > 0)
-    for vidx, video in enumerate(folders):
-        images = sorted(glob.glob(video + "*"))
-        root_dir = "/".join(video.split("/")[:-2])
-        outs = [im.replace(root_dir, out).replace(".png", ".flo").replace(".jpg", ".flo") for im in images]
-        os.makedirs(video.replace(root_dir, out), exist_ok=True)
-        t = time()
-        pairs = list(zip(images[:-1], images[1:], outs))
-        # frames are decoded ahead on a thread pool (every frame once), the .flo files are written by a background thread;
-        # the main thread only feeds the GPU.  Same bytes as the serial loop of the reference (:94-102).
-        decoded = iop.prefetch(images, jpeg.loader())       # (PREMVOS_GPU_JPEG=1: entropy decode here, the rest on the GPU)
-        frames: Dict[str, object] = {}
+    ok = False
+    try:
+        for vidx, video in enumerate(folders):
+            images = sorted(glob.glob(video + "*"))
+            root_dir = "/".join(video.split("/")[:-2])
+            outs = [im.replace(root_dir, out).replace(".png", ".flo").replace(".jpg", ".flo") for im in images]
+            os.makedirs(video.replace(root_dir, out), exist_ok=True)
+            t = time()
+            pairs = list(zip(images[:-1], images[1:], outs))
+            # frames are decoded ahead on a thread pool (every frame once), the .flo files are written by a background thread;
+            # the main thread only feeds the GPU.  Same bytes as the serial loop of the reference (:94-102).
+            decoded = iop.prefetch(images, jpeg.loader())       # (PREMVOS_GPU_JPEG=1: entropy decode here, the rest on the GPU)
+            frames: Dict[str, object] = {}
 
-        def frame(fn):
-            while fn not in frames:
-                k = images[len(frames) + frame.dropped]
-                fr = next(decoded)
-                # a frame is the second image of one pair and the first of the next: a GPU-decoded frame is finished once
-                frames[k] = jpeg.to_device(fr) if isinstance(fr, jpeg.Decoded) else fr
-            return frames[fn]
-        frame.dropped = 0
-        for s0 in range(0, len(pairs), batch):
-            chunk = pairs[s0:s0 + batch]
-            for a, b_, _ in chunk:
-                frame(a), frame(b_)
-            same = all(frames[a].shape == frames[chunk[0][0]].shape and frames[b_].shape == frames[chunk[0][0]].shape
-                       for a, b_, _ in chunk)
-            groups = [chunk] if same else [[c] for c in chunk]
-            for g in groups:
-                if len(g) not in stages:
-                    stages[len(g)] = FlowStage(net=net, batch=len(g))
-                st = stages[len(g)]
-                im1 = jpeg.stack_frames([frames[a] for a, _, _ in g], st.device)
-                im2 = jpeg.stack_frames([frames[b_] for _, b_, _ in g], st.device)
-                flo = st.run(im1, im2).cpu().numpy()
-                for k, (_, _, flow_fn) in enumerate(g):
-                    writer.submit(writeFlowFile, flow_fn, flo[k])
-            for a, _, _ in chunk:                       # only the second image of the last pair is needed again
-                if a in frames:
-                    del frames[a]
-                    frame.dropped += 1
-        n = max(len(images) - 1, 1)
-        print("video", vidx, "finished in", time() - t, "seconds.", n, "images at", (time() - t) / n, "per image.")
-    writer.close()
+            def frame(fn):
+                while fn not in frames:
+                    k = images[len(frames) + frame.dropped]
+                    fr = next(decoded)
+                    # a frame is the second image of one pair and the first of the next: a GPU-decoded frame is finished once
+                    frames[k] = jpeg.to_device(fr) if isinstance(fr, jpeg.Decoded) else fr
+                return frames[fn]
+            frame.dropped = 0
+            for s0 in range(0, len(pairs), batch):
+                chunk = pairs[s0:s0 + batch]
+                for a, b_, _ in chunk:
+                    frame(a), frame(b_)
+                same = all(frames[a].shape == frames[chunk[0][0]].shape and frames[b_].shape == frames[chunk[0][0]].shape
+                           for a, b_, _ in chunk)
+                groups = [chunk] if same else [[c] for c in chunk]
+                for g in groups:
+                    if len(g) not in stages:
+                        stages[len(g)] = FlowStage(net=net, batch=len(g))
+                    st = stages[len(g)]
+                    im1 = jpeg.stack_frames([frames[a] for a, _, _ in g], st.device)
+                    im2 = jpeg.stack_frames([frames[b_] for _, b_, _ in g], st.device)
+                    flo = st.run(im1, im2).cpu().numpy()
+                    for k, (_, _, flow_fn) in enumerate(g):
+                        writer.submit(writeFlowFile, flow_fn, flo[k])
+                for a, _, _ in chunk:                       # only the second image of the last pair is needed again
+                    if a in frames:
+                        del frames[a]
+                        frame.dropped += 1
+            n = max(len(images) - 1, 1)
+            print("video", vidx, "finished in", time() - t, "seconds.", n, "images at", (time() - t) / n, "per image.")
+        ok = True
+    finally:
+        try:                                    # queued .flo files are written even when a later frame failed
+            writer.close()
+        except BaseException:                   # noqa: BLE001 -- a writer error must not replace the error that got us here
+            if ok:
+                raise
     return 0
 
 

@@ -115,5 +115,9 @@ class Writer:
         return self
 
     def __exit__(self, *exc):
-        self.close()
+        try:
+            self.close()
+        except BaseException:                       # noqa: BLE001
+            if exc[0] is None:                      # never replace an exception that is already in flight
+                raise
         return False

@@ -31,8 +31,81 @@ def shard_videos(videos: List[str], world: int, rank: int) -> List[str]:
     return videos[s:e]
 
 
+def env_rank() -> Tuple[int, int, int]:
+    """(world, rank, local rank) of this process as torch.distributed.run exports them; (1, 0, 0) outside it."""
+    import os
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def bind_device() -> int:
+    """One process per GPU: make LOCAL_RANK's device the current one (so "cuda" means it everywhere below).  Returns its index."""
+    _, _, local = env_rank()
+    n = torch.cuda.device_count()
+    if n:
+        torch.cuda.set_device(local % n)
+    return local % max(n, 1)
+
+
+def my_videos(videos: List[str]) -> List[str]:
+    """The stage drivers under ``python -m torch.distributed.run --nproc-per-node N -m premvos_amd.<stage>.driver ...``: rank r
+    takes the r-th contiguous slice of the video list -- the reference's ``curr_run_num / total_to_run`` scheme
+    (DAVISFewShotSegmentationDataset.py:130-150, merge.py:66-67,126-128) with the slice picked by the launcher instead of by
+    editing the file; results meet on the filesystem, no process group is needed.  Outside torch.distributed.run: all videos."""
+    world, rank, _ = env_rank()
+    return shard_videos(list(videos), world, rank) if world > 1 else list(videos)
+
+
 def max_shard(n_items: int, world: int) -> int:
     return (max(n_items, 0) + world - 1) // world
+
+
+def balance_videos(frame_counts: List[int], world: int) -> List[List[int]]:
+    """Whole videos per rank, longest video first onto the least loaded rank (ties: lower rank, lower index) -- the same
+    granularity as the reference's hand-edited list slices (``shard_videos``), but balanced by frame count.  Deterministic;
+    returns the video indices of every rank in ascending order."""
+    load, out = [0] * world, [[] for _ in range(world)]
+    for v in sorted(range(len(frame_counts)), key=lambda i: (-frame_counts[i], i)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += frame_counts[v]
+        out[r].append(v)
+    return [sorted(x) for x in out]
+
+
+def plan_shards(frame_counts: List[int], world: int, rank: int, chunk: int,
+                scheme: str = "balanced") -> List[Tuple[int, int, int]]:
+    """The work of ``rank``: a list of (video index, first frame, end frame).
+
+    * at least ``world`` videos: whole videos per rank (``scheme`` = "balanced": by frame count; "contiguous": the reference's
+      own slice of the sorted list, DAVISFewShotSegmentationDataset.py:130-150 / merge.py:66-67,126-128);
+    * fewer videos than ranks: every video is cut into contiguous frame ranges.  The cuts fall on multiples of ``chunk`` (the
+      driver's launch batch), i.e. ranks share out the CHUNKS a one-rank run would form: every chunk then holds the same
+      frames -- hence runs the same kernels on the same data and writes the same bytes -- whatever the number of ranks.
+      Frame pair t = (t, t+1) belongs to the rank that owns frame t, so a rank whose range ends before the video does also
+      READS frame ``end`` (second image of its last pair, script_pwc_multi.py:100-102); it writes nothing for it.
+      Successive videos start their split at a rotated rank, so the ranks holding one chunk more are not always the first ones.
+    """
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    if chunk <= 0:
+        raise ValueError("chunk must be positive")
+    nv = len(frame_counts)
+    if nv >= world:
+        if scheme == "contiguous":
+            s, e = shard_range(nv, world, rank)
+            mine = list(range(s, e))
+        elif scheme == "balanced":
+            mine = balance_videos(frame_counts, world)[rank]
+        else:
+            raise ValueError(f"unknown sharding scheme {scheme!r}")
+        return [(v, 0, frame_counts[v]) for v in mine if frame_counts[v] > 0]
+    out, rot = [], 0
+    for v, n in enumerate(frame_counts):
+        n_chunks = -(-n // chunk)
+        cs, ce = shard_range(n_chunks, world, (rank + rot) % world)
+        if ce > cs:
+            out.append((v, cs * chunk, min(ce * chunk, n)))
+        rot = (rot + world - n_chunks % world) % world
+    return out
 
 
 def gather_padded(local: torch.Tensor, n_valid: int, capacity: int, dst: int = 0,
@@ -69,7 +142,7 @@ class ResultExchange:
     SMALL_COLS_FIXED = 2 * 20 * 5 + 2          # general + specific: 20 boxes x (4 + prob), + the two detection counts
 
     def __init__(self, batch: int, h: int, w: int, boxes_per_frame: int, device, dst: int = 0, group=None,
-                 pack_bits=None, unpack_bits=None):
+                 pack_bits=None, unpack_bits=None, slots: int = 2):
         self.B, self.H, self.W, self.P, self.dst, self.group = batch, h, w, boxes_per_frame, dst, group
         self.device = torch.device(device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -81,16 +154,23 @@ class ResultExchange:
         self.off_mask = self.flow_bytes
         self.off_small = (self.off_mask + self.mask_bytes + 15) // 16 * 16
         self.nbytes = self.off_small + batch * self.small_cols * 4
-        self.packed = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
+        # two slots: the gather of step i (async) is still reading slot i % 2 while step i + 1 is packed into the other one
+        self._packed = [torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(slots)]
+        self.packed = self._packed[0]
         self.host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo" and self.device.type != "cpu"
         gdev = torch.device("cpu") if self.host_staged else self.device
-        self.gathered = ([torch.zeros(self.nbytes, dtype=torch.uint8, device=gdev) for _ in range(self.world)]
-                         if self.rank == dst else None)
+        self._gathered = [([torch.zeros(self.nbytes, dtype=torch.uint8, device=gdev) for _ in range(self.world)]
+                           if self.rank == dst else None) for _ in range(slots)]
+        self.gathered = self._gathered[0]
+        self._work = [None] * slots
+        self._send = [None] * slots
+        self._n = 0
         self._pack_bits, self._unpack_bits = pack_bits or _hip_pack_bits, unpack_bits or _hip_unpack_bits
 
-    def pack(self, r) -> torch.Tensor:
+    def pack(self, r, slot: int = 0) -> torch.Tensor:
         """r: the dict FramePipeline.step returns.  Fills and returns this rank's byte buffer."""
         B = self.B
+        self.packed = self._packed[slot]
         self.packed[:self.flow_bytes].view(torch.float32).view(B, self.H, self.W, 2).copy_(r["flow"])
         self._pack_bits(r["masks"].contiguous().view(-1), self.packed[self.off_mask:self.off_mask + self.mask_bytes])
         small = self.packed[self.off_small:].view(torch.float32).view(B, self.small_cols)
@@ -109,6 +189,34 @@ class ResultExchange:
         send = buf.cpu() if self.host_staged else buf
         dist.gather(send, self.gathered if self.rank == self.dst else None, dst=self.dst, group=self.group)
         return self.gathered
+
+    def exchange_async(self, r):
+        """pack + the single gather, NOT waited for: the collective of step i runs while step i + 1 computes (RCCL: on its own
+        stream behind the pack kernels; gloo: on the backend's thread).  A slot is reused every ``slots`` calls, after waiting for
+        the gather that last used it.  Returns the slot; ``wait(slot)`` (or ``flush()``) makes ``gathered_slot(slot)`` valid."""
+        slot = self._n % len(self._packed)
+        self._n += 1
+        self.wait(slot)
+        buf = self.pack(r, slot)
+        if not dist.is_initialized():
+            self._gathered[slot] = [buf]
+            return slot
+        send = self._send[slot] = (buf.cpu() if self.host_staged else buf)      # kept alive until the gather is done
+        self._work[slot] = dist.gather(send, self._gathered[slot] if self.rank == self.dst else None, dst=self.dst,
+                                       group=self.group, async_op=True)
+        return slot
+
+    def wait(self, slot: int):
+        w, self._work[slot] = self._work[slot], None
+        if w is not None:
+            w.wait()
+
+    def flush(self):
+        for s in range(len(self._work)):
+            self.wait(s)
+
+    def gathered_slot(self, slot: int):
+        return self._gathered[slot]
 
     def unpack(self, buf: torch.Tensor):
         """One rank's byte buffer -> dict of tensors (masks as {0,1} bytes), on ``buf``'s device."""

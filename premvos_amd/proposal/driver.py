@@ -221,6 +221,8 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
         pre = "/".join(davis_name.split("/")[:-1])
         with open(davis_name) as f:
             seqs = [ln.rstrip() for ln in f if ln.rstrip()]
+        from .. import parallel
+        seqs = parallel.my_videos(seqs)         # under torch.distributed.run: this rank's slice of the video list
         imgs = []
         for s in seqs:
             imgs += sorted(glob.glob(pre + "/" + s + "/*"))
@@ -305,6 +307,8 @@ def main(argv: Optional[List[str]] = None) -> int:
         raise SystemExit("only --forward (inference) is on the hot path; training is out of scope")
     if not a.agnostic:
         raise SystemExit("the shipped pipeline runs --agnostic (NUM_CLASS=2)")
+    from .. import parallel
+    parallel.bind_device()                      # one rank per GPU under torch.distributed.run
     w = load_weights(a.load)
     pred = OfflinePredictor(ProposalNet(w, num_blocks=infer_num_blocks(w)))
     forward(pred, a.forward, a.forward_dataset, a.davis_name, a.generic_images_folder, a.generic_images_pattern)

@@ -327,6 +327,10 @@ def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_d
     from .. import io_pipeline as iop
     group = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
     files = sorted(glob.glob(os.path.join(bb_input_dir, "*", "*.json")))
+    from .. import parallel
+    if parallel.env_rank()[0] > 1:              # under torch.distributed.run: this rank's slice of the videos (the reference's
+        mine = set(parallel.my_videos(sorted({os.path.basename(os.path.dirname(f)) for f in files})))   # curr_run_num scheme)
+        files = [f for f in files if os.path.basename(os.path.dirname(f)) in mine]
     # optional binary fast path: <frame>.pmv with bit-packed masks instead of <frame>.json with RLE strings;
     # read by this package's ReID stage, `python -m premvos_amd.sidecar --to-json` gives MergeTrack its JSON back
     sidecar = os.environ.get("PREMVOS_SIDECAR", "0") == "1" if sidecar is None else sidecar
@@ -391,6 +395,8 @@ def main(argv: Optional[List[str]] = None) -> int:
     argv = sys.argv[1:] if argv is None else argv
     assert len(argv) in (1, 2), "usage: driver.py <config> [update_config_string]"
     cfg = Config(argv[0], argv[1] if len(argv) > 1 else "")
+    from .. import parallel
+    parallel.bind_device()                      # one rank per GPU under torch.distributed.run
     w = load_weights(cfg.string("load"))
     engine = RefinementEngine(RefinementNet(w, infer_num_middle(w)))
     forward_directory(engine, cfg.dir("image_input_dir"), cfg.dir("bb_input_dir"), cfg.dir("output_dir"))

@@ -267,6 +267,7 @@ class RefinementNet:
         self.packed: Dict[str, ops.PackedConv] = {}
         self.packed_dw: Dict[str, PackedDW] = {}
         self._plans: Dict[tuple, _Plan] = {}
+        self._plans_lock = __import__("threading").Lock()
         self.max_plans = int(os.environ.get("PREMVOS_REFINE_MAX_PLANS", "12"))
         head = ("image_pooling", "aspp", "concat_projection", "decoder/")
         for k, v in weights.items():
@@ -285,18 +286,26 @@ class RefinementNet:
         """``lane`` selects an independent workspace (same weights) so several calls can be in flight; ``frames`` > 1
         builds a plan that refines that many frames (P boxes each) as one batch."""
         key = (P, H, W, with_posterior, lane, frames)
-        p = self._plans.get(key)
-        if p is None:
-            with ops.BUILD_LOCK:                  # lanes of the file drivers run on several threads; building + tuning +
-                p = self._plans.get(key)          # graph capture of a plan is done by one of them at a time
-                if p is None:
-                    p = _Plan(self, P, H, W, with_posterior, frames)
-                    if self.use_graph:
-                        torch.cuda.synchronize()  # capture must not race kernels of another lane's stream
-                        p.capture()
+        with self._plans_lock:                    # LRU: a hit moves the plan to the young end (dicts keep insertion order)
+            p = self._plans.pop(key, None)
+            if p is not None:
+                self._plans[key] = p
+                return p
+        with ops.BUILD_LOCK:                      # lanes of the file drivers run on several threads; building + tuning +
+            with self._plans_lock:                # graph capture of a plan is done by one of them at a time
+                p = self._plans.get(key)
+            if p is None:
+                p = _Plan(self, P, H, W, with_posterior, frames)
+                if self.use_graph:
+                    torch.cuda.synchronize()      # capture must not race kernels of another lane's stream
+                    p.capture()
+                with self._plans_lock:
                     self._plans[key] = p
-                    while len(self._plans) > self.max_plans:          # every plan holds a full Xception activation set
-                        self._plans.pop(next(iter(self._plans)))      # drop the oldest (dicts keep insertion order)
+                    # every plan holds a full Xception activation set: evict the least recently used one OF THIS LANE first
+                    # (the other lane's plan may be executing on its own thread right now), any lane only beyond that
+                    while len(self._plans) > self.max_plans:
+                        mine = [k for k in self._plans if k[4] == lane and k != key]
+                        self._plans.pop(mine[0] if mine else next(k for k in self._plans if k != key))
         return p
 
     def refine(self, frame_rgb: torch.Tensor, boxes_y0x0y1x1: torch.Tensor, max_boxes: Optional[int] = None,

@@ -13,7 +13,10 @@ This is SURVEY 8(f) rank 4 (host / format fast paths); the per-stage drivers (pr
 remain the drop-in twins of the reference's scripts.  rocJPEG is not part of the image, so decoding stays on the host
 (PIL / libjpeg-turbo) on PREMVOS_IO_THREADS threads.
 
-    python -m premvos_amd.stream --root <PReMVOS root> [--batch 8] [weights as in tools/run_stages.py]
+    python -m premvos_amd.stream --root <PReMVOS root> [--batch 8] [--gpus N [--gather]] [weights as in tools/run_stages.py]
+
+``--gpus N``: one process per GPU (torch.distributed; RCCL), the videos -- or, with fewer videos than GPUs, chunk-aligned frame
+ranges of each video -- shared out by premvos_amd.parallel.plan_shards; the output tree is byte-identical to the one-GPU run.
 """
 from __future__ import annotations
 
@@ -132,9 +135,12 @@ class StreamPipeline:
         return None
 
     # ---- the driver ---------------------------------------------------------------------------------------------------
-    def run_sequences(self, folders: List[str]) -> int:
+    def run_sequences(self, folders: List[str], shards: Optional[List[tuple]] = None, writer=None) -> int:
+        """``shards``: (index into folders, first frame, end frame) items (premvos_amd.parallel.plan_shards); None = every
+        frame of every folder.  Returns the number of frames this process owned."""
         errors: List[BaseException] = []
-        writer = iop.Writer(enabled=True)
+        own_writer = writer is None
+        writer = iop.Writer(enabled=True) if own_writer else writer
         q_flow, q_g, q_s, q_rg, q_rs = (queue.Queue(maxsize=3) for _ in range(5))
         q_join: "queue.Queue" = queue.Queue(maxsize=3)
 
@@ -157,54 +163,92 @@ class StreamPipeline:
                    _stage_thread("prop-specific", lambda c: self._proposals(1, c, writer), q_s, q_rs, errors),
                    _stage_thread("refine", lambda it: self._refine(it, writer), q_join, None, errors), joiner]
         n_frames = 0
-        for video in folders:
-            images = sorted(glob.glob(os.path.join(video, "*")))
-            seq = video.rstrip("/").split("/")[-1]
+        if shards is None:
+            shards = [(v, 0, None) for v in range(len(folders))]
+
+        def finish(fr):
             # PREMVOS_GPU_JPEG=1: the pool only Huffman-decodes; this thread finishes each frame ONCE on the GPU (inverse DCT,
             # up-sampling, colour conversion) and the four stage threads share the HBM copy instead of uploading it each
-            decoded = iop.prefetch(images, jpeg.loader())
-            names = [os.path.splitext(os.path.basename(fn))[0] for fn in images]
-            cur: List[np.ndarray] = []
-            cur_names: List[str] = []
-            pending = None                           # a full chunk waiting for the first frame of its successor
+            if isinstance(fr, jpeg.Decoded):
+                with torch.cuda.stream(self.streams["decode"]):
+                    fr = jpeg.to_device(fr, self.dev)
+                self.streams["decode"].synchronize()
+            return fr
 
-            def emit(chunk_frames, chunk_names, nxt):
-                if nxt is not None and nxt.shape != chunk_frames[0].shape:
-                    nxt = None                       # (a size change inside a video: the reference would fail in cv2 here)
-                item = (seq, chunk_names, chunk_frames, nxt)
-                for q in (q_flow, q_g, q_s):
-                    q.put(item)
-
-            for name, fr in zip(names, decoded):
+        try:
+            for v, first, end in shards:
+                video = folders[v]
+                images = sorted(glob.glob(os.path.join(video, "*")))
+                seq = video.rstrip("/").split("/")[-1]
+                for names, frames, nxt in iter_chunks(images, first, end, self.batch, jpeg.loader(), finish):
+                    if errors:
+                        break
+                    item = (seq, names, frames, nxt)
+                    for q in (q_flow, q_g, q_s):
+                        q.put(item)
+                    n_frames += len(frames)
                 if errors:
                     break
-                if isinstance(fr, jpeg.Decoded):
-                    with torch.cuda.stream(self.streams["decode"]):
-                        fr = jpeg.to_device(fr, self.dev)
-                    self.streams["decode"].synchronize()
-                if pending is not None:
-                    emit(pending[0], pending[1], fr)
-                    pending = None
-                if cur and fr.shape != cur[0].shape:
-                    emit(cur, cur_names, None)
-                    cur, cur_names = [], []
-                cur.append(fr)
-                cur_names.append(name)
-                n_frames += 1
-                if len(cur) == self.batch:
-                    pending, cur, cur_names = (cur, cur_names), [], []
-            if pending is not None:
-                emit(pending[0], pending[1], cur[0] if cur else None)
-            if cur:
-                emit(cur, cur_names, None)
-        for q in (q_flow, q_g, q_s):
-            q.put(_END)
-        for t in threads:
-            t.join()
-        writer.close()
+        except BaseException as e:                   # a decode / upload error on this thread: the stage threads must still end
+            errors.insert(0, e)
+        finally:
+            for q in (q_flow, q_g, q_s):
+                q.put(_END)
+            for t in threads:
+                t.join()
+            if own_writer:
+                try:
+                    writer.close()
+                except BaseException as e:           # noqa: BLE001 -- reported below unless a stage failed first
+                    errors.append(e)
         if errors:
             raise errors[0]
         return n_frames
+
+
+def iter_chunks(images: List[str], first: int, end: Optional[int], batch: int, load, finish=lambda fr: fr):
+    """Host logic of one shard, free of GPU code (tests/test_cpu_parallel.py drives it with a fake loader): frames
+    [first, end) of the sorted file list ``images`` as chunks ``(names, frames, next_frame)`` of at most ``batch`` frames of
+    one size; ``next_frame`` is the first frame after the chunk -- the second image of the chunk's last flow pair
+    (script_pwc_multi.py:100-102) -- or None at the end of the video or in front of a change of size.  A shard that stops
+    before the video does (``end`` < len(images): another rank owns the rest) decodes frame ``end`` too, for that purpose
+    only.  Every frame is decoded once, ahead of the consumer (io_pipeline.prefetch)."""
+    n = len(images)
+    end = n if end is None else min(end, n)
+    if first >= end:
+        return
+    todo = images[first:min(end + 1, n)]
+    names = [os.path.splitext(os.path.basename(fn))[0] for fn in todo]
+    decoded = iop.prefetch(todo, load)
+    cur, cur_names = [], []
+    pending = None                               # a full chunk waiting for the first frame of its successor
+
+    def chunk(frames, chunk_names, nxt):
+        if nxt is not None and nxt.shape != frames[0].shape:
+            nxt = None                           # (a size change inside a video: the reference would fail in cv2 here)
+        return chunk_names, frames, nxt
+
+    for k, (name, fr) in enumerate(zip(names, decoded)):
+        fr = finish(fr)
+        if pending is not None:
+            yield chunk(pending[0], pending[1], fr)
+            pending = None
+        if first + k >= end:                     # the boundary frame of the next rank's range: read, never owned
+            if cur:                              # (a range that is not a multiple of the batch: its last chunk is short)
+                yield chunk(cur, cur_names, fr)
+                cur, cur_names = [], []
+            break
+        if cur and fr.shape != cur[0].shape:
+            yield chunk(cur, cur_names, None)
+            cur, cur_names = [], []
+        cur.append(fr)
+        cur_names.append(name)
+        if len(cur) == batch:
+            pending, cur, cur_names = (cur, cur_names), [], []
+    if pending is not None:
+        yield chunk(pending[0], pending[1], cur[0] if cur else None)
+    if cur:
+        yield chunk(cur, cur_names, None)
 
 
 def _dump_json(fn, obj):
@@ -213,16 +257,148 @@ def _dump_json(fn, obj):
         json.dump(obj, f)
 
 
+def _write_bytes(fn, data: bytes):
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    with open(fn, "wb") as f:
+        f.write(data)
+
+
+class GatherWriter:
+    """``--gather``: instead of writing its files, a rank keeps (path, bytes) and hands them to the merge rank -- the rank that
+    will run the CPU-side MergeTrack -- in ONE padded gather per shard item (premvos_amd.parallel.gather_padded; RCCL over
+    xGMI on GPUs, gloo in the CPU tests); the merge rank writes every rank's files.  Same bytes as the per-rank writers: the
+    payloads are produced by the same functions (flo_bytes / json.dumps)."""
+
+    def __init__(self, device, dst: int = 0):
+        self.files: List[tuple] = []
+        self.device, self.dst = device, dst
+        self._lock = threading.Lock()
+
+    def submit(self, fn, path, obj):
+        from .flow.driver import flo_bytes, writeFlowFile
+        data = flo_bytes(obj) if fn is writeFlowFile else json.dumps(obj).encode() if fn is _dump_json else None
+        if data is None:
+            raise TypeError(f"GatherWriter cannot serialise the payload of {fn}")
+        with self._lock:
+            self.files.append((path, data))
+
+    @staticmethod
+    def pack(files) -> bytes:
+        import struct
+        parts = [struct.pack("<I", len(files))]
+        for path, data in files:
+            pb = path.encode()
+            parts += [struct.pack("<IQ", len(pb), len(data)), pb, data]
+        return b"".join(parts)
+
+    @staticmethod
+    def unpack(buf: bytes):
+        import struct
+        (n,), off, out = struct.unpack_from("<I", buf, 0), 4, []
+        for _ in range(n):
+            pl, dl = struct.unpack_from("<IQ", buf, off)
+            off += 12
+            out.append((buf[off:off + pl].decode(), bytes(buf[off + pl:off + pl + dl])))
+            off += pl + dl
+        return out
+
+    def flush(self) -> int:
+        """Collective: every rank calls it the same number of times.  Returns the number of files written (merge rank)."""
+        import torch.distributed as dist
+        from .parallel import gather_padded
+        with self._lock:
+            files, self.files = self.files, []
+        raw = np.frombuffer(self.pack(files), dtype=np.uint8).copy()
+        local = torch.from_numpy(raw).to(self.device)
+        cap = torch.tensor([local.numel()], dtype=torch.int64, device=self.device)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        got = gather_padded(local, local.numel(), int(cap.item()), dst=self.dst)
+        n = 0
+        if got is not None:
+            for t in got:
+                for path, data in self.unpack(t.cpu().numpy().tobytes()):
+                    _write_bytes(path, data)
+                    n += 1
+        return n
+
+    def close(self):
+        pass
+
+
+def _self_launch(gpus: int, argv: List[str]) -> int:
+    """``python -m premvos_amd.stream --gpus N`` outside torch.distributed: start N ranks, one process per GPU."""
+    import socket
+    import subprocess
+    backend = os.environ.get("PREMVOS_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < gpus and backend == "nccl":
+        raise SystemExit(f"premvos_amd.stream --gpus {gpus}: this node exposes {ndev} GPU(s) (RCCL needs one device per rank)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "premvos_amd.stream"] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def run(root: str, seq_file: str, flow_weights: str, general_weights: str, specific_weights: str, refinement_weights: str,
-        batch: int = 8, out: str = "output/intermediate") -> int:
+        batch: int = 8, out: str = "output/intermediate", shard: str = "balanced", gather: bool = False) -> int:
+    """One rank of the job (the only one when WORLD_SIZE is unset): device = LOCAL_RANK, work = its shards of the videos of
+    ``seq_file`` (premvos_amd.parallel.plan_shards: whole videos when there are at least as many as ranks -- the reference's
+    granularity, DAVISFewShotSegmentationDataset.py:130-150, merge.py:66-67,126-128 -- else chunk-aligned frame ranges with the
+    boundary frame read as the second image of the last pair, script_pwc_multi.py:100-102).  No data-path collective; every
+    rank writes its own files into the shared tree (the reference's filesystem rendezvous) unless ``gather``.  Returns the
+    frames of the whole job."""
+    import torch.distributed as dist
+    from . import ops
+    from .parallel import plan_shards
     os.chdir(root)
-    pipe = StreamPipeline(flow_weights, general_weights, specific_weights, refinement_weights, batch, out)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("PREMVOS_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s) visible: one device per rank is required")
+    torch.cuda.set_device(local % max(ndev, 1))       # "cuda" below = this rank's device (gloo: ranks may share one, for tests)
+    if world > 1 and not dist.is_initialized():
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60))
     with open(seq_file) as f:
         folders = [ln.rstrip() for ln in f if ln.rstrip()]
-    return pipe.run_sequences(folders)
+    counts = [len(glob.glob(os.path.join(v, "*"))) for v in folders]
+    plans = [plan_shards(counts, world, r, batch, shard) for r in range(world)]
+    pipe = StreamPipeline(flow_weights, general_weights, specific_weights, refinement_weights, batch, out)
+    n = 0
+    if gather and world > 1:
+        gw = GatherWriter(torch.device("cuda") if backend == "nccl" else torch.device("cpu"))
+        for k in range(max(len(p) for p in plans)):          # one gather per shard item, empty ones to keep the ranks in step
+            if k < len(plans[rank]):
+                n += pipe.run_sequences(folders, [plans[rank][k]], writer=gw)
+            gw.flush()
+    else:
+        n = pipe.run_sequences(folders, plans[rank])
+    total = n
+    if world > 1:
+        t = torch.tensor([n], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)                                   # also the job's final barrier: every file is on disk after it
+        total = int(t.item())
+    if rank == 0:
+        # which configurations computed these files (ops.tune_info): the shipped table's hash + how many signatures it lacked
+        _dump_json(os.path.join(os.path.dirname(out.rstrip("/")) or ".", "premvos_amd_manifest.json"),
+                   {"frames": total, "ranks": world, "chunk": batch, "sharding": shard,
+                    "shards": [[[folders[v], a, b] for v, a, b in p] for p in plans], "conv_configurations": ops.tune_info()})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return total
 
 
 def main(argv: Optional[List[str]] = None) -> int:
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--root", default=".")
     ap.add_argument("--seq_file", default="seq_to_run.txt")
@@ -231,9 +407,21 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--specific_weights", default="weights/PReMVOS_weights/proposal_net/specific_weights/proposal_specific_weights")
     ap.add_argument("--refinement_weights", default="weights/PReMVOS_weights/refinement_net/specific_weights/refinement_specific_weights")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PREMVOS_STREAM_BATCH", "8")), help="frames per chunk")
+    ap.add_argument("--gpus", type=int, default=int(os.environ.get("WORLD_SIZE", "1")),
+                    help="ranks = GPUs of this node; > 1 outside torch.distributed.run starts the ranks itself")
+    ap.add_argument("--shard", default="balanced", choices=["balanced", "contiguous"],
+                    help="whole-video assignment when there are at least --gpus videos: by frame count, or the reference's slices")
+    ap.add_argument("--gather", action="store_true",
+                    help="hand every rank's files to rank 0 (one gather per shard item) instead of writing them per rank")
     a = ap.parse_args(argv)
-    n = run(a.root, a.seq_file, a.flow_weights, a.general_weights, a.specific_weights, a.refinement_weights, a.batch)
-    print("frames:", n)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(a.gpus, argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} was started with WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
+    n = run(a.root, a.seq_file, a.flow_weights, a.general_weights, a.specific_weights, a.refinement_weights, a.batch,
+            shard=a.shard, gather=a.gather)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("frames:", n)
     return 0
 
 

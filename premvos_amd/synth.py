@@ -172,6 +172,31 @@ def video_frames(batch: int, h: int, w: int, rank: int = 0):
     return torch.stack(first).contiguous(), torch.stack(second).contiguous()
 
 
+def clip_frames(first: int, end: int, h: int, w: int, seed: int = 77) -> torch.Tensor:
+    """Frames [first, end) of ONE seeded synthetic video as uint8 RGB [n,H,W,3]: a smooth noise field drifting by a sub-pixel
+    step per frame, so frame t is the same bytes whichever rank (and whichever range) asks for it -- what the strong-scaling
+    bench shards (bench.py --scaling strong)."""
+    rng = np.random.default_rng(seed)
+    pad = 40
+    coarse = torch.from_numpy(rng.random((3, h // 8 + 3 + pad // 4, w // 8 + 3 + pad // 4), dtype=np.float32))[None]
+    big = F.interpolate(coarse, size=(h + 2 * pad, w + 2 * pad), mode="bicubic", align_corners=True).clamp(0, 1)
+    out = []
+    for t in range(first, end):
+        dx, dy = pad * math.sin(0.011 * t + 0.3) * 0.9, pad * math.cos(0.007 * t) * 0.9     # stays inside the padded field
+        gy = 2 * (torch.arange(h, dtype=torch.float32) + pad + dy) / (h + 2 * pad - 1) - 1
+        gx = 2 * (torch.arange(w, dtype=torch.float32) + pad + dx) / (w + 2 * pad - 1) - 1
+        grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], -1)[None]
+        fr = F.grid_sample(big, grid, mode="bilinear", align_corners=True)[0]
+        out.append((fr.permute(1, 2, 0) * 255).round().to(torch.uint8))
+    return torch.stack(out).contiguous() if out else torch.zeros((0, h, w, 3), dtype=torch.uint8)
+
+
+def clip_boxes(first: int, end: int, per_frame: int, h: int, w: int, seed: int = 4321) -> torch.Tensor:
+    """[n,P,4] boxes of frames [first, end) of the clip, a function of the frame index only."""
+    return torch.cat([boxes(1, per_frame, h, w, rank=seed + 7919 * t - 4321) for t in range(first, end)]) if end > first \
+        else torch.zeros((0, per_frame, 4), dtype=torch.float32)
+
+
 def boxes(batch: int, per_frame: int, h: int, w: int, rank: int = 0) -> torch.Tensor:
     """[B,P,4] (y0,x0,y1,x1): seeded uniform boxes with w,h in [40,400] clipped to the frame."""
     rng = np.random.default_rng(4321 + rank)

@@ -137,6 +137,56 @@ def test_host_decoder_refuses_what_it_does_not_cover_and_reports_corrupt_files()
     assert b"coefficient buffer" in lib.premvos_last_error()
 
 
+def test_host_decoder_survives_malformed_tables_huge_headers_and_random_damage():
+    """an over-subscribed DHT (more codes of a length than the code space holds) used to overrun the
+    512-entry fast table on the stack; SOF dimensions were unbounded.  Now: clean errors, and a seeded fuzz over truncations and
+    byte flips of good files never crashes -- every outcome is a decoded frame, ``Unsupported`` or a ``PremvosError``."""
+    from premvos_amd import _lib, jpeg
+    # SOI + one DHT whose counts claim 255 one-bit codes (parse_header's cnt <= 256 let it through)
+    counts = bytes([255] + [0] * 15)
+    seg = bytes([0x00]) + counts + bytes(255)
+    bad = b"\xff\xd8\xff\xc4" + (len(seg) + 2).to_bytes(2, "big") + seg
+    with pytest.raises(_lib.PremvosError, match="prefix code"):
+        jpeg.header(bad)
+    for counts in ([0, 5] + [0] * 14, [2, 1] + [0] * 14, [1, 1, 1, 1, 1, 1, 1, 1, 255] + [0] * 7):      # 5 two-bit codes; 2 + 1 > 4 ...
+        n = sum(counts)
+        seg = bytes([0x10]) + bytes(counts) + bytes(range(n % 256)) * 1 + bytes(max(0, n - n % 256))
+        seg = seg[:17 + n]
+        data = b"\xff\xd8\xff\xc4" + (len(seg) + 2).to_bytes(2, "big") + seg
+        with pytest.raises(_lib.PremvosError, match="prefix code|bad DHT"):
+            jpeg.header(data)
+    # a complete (exactly full) code is fine: 2 one-bit codes
+    good = jpeg_bytes(picture(64, 64), quality=90)
+    assert jpeg.header(good).width == 64
+    # a header claiming 65535 x 65535 pixels must not make the caller allocate 8 GB
+    sof = good.index(b"\xff\xc0")
+    huge = bytearray(good)
+    huge[sof + 5:sof + 9] = b"\xff\xff\xff\xff"
+    with pytest.raises(_lib.PremvosError, match="64 Mpixel"):
+        jpeg.header(bytes(huge))
+    # fuzz: truncations + byte flips of three files (4:2:0 with optimised tables, 4:4:4, grey)
+    rng = np.random.default_rng(7)
+    files = [jpeg_bytes(picture(40, 56), quality=70, subsampling=2, optimize=True), jpeg_bytes(picture(33, 47), quality=95, subsampling=0),
+             jpeg_bytes(picture(24, 24, grey=True), quality=85)]
+    outcomes = {"ok": 0, "unsupported": 0, "error": 0}
+    for f in files:
+        for trial in range(150):
+            b = bytearray(f)
+            if trial % 3 == 0:
+                b = b[:int(rng.integers(2, len(b)))]
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+            try:
+                d = jpeg.entropy_decode(bytes(b))
+                assert d.coef.numel() >= d.info.coef_count
+                outcomes["ok"] += 1
+            except jpeg.Unsupported:
+                outcomes["unsupported"] += 1
+            except _lib.PremvosError:
+                outcomes["error"] += 1
+    assert sum(outcomes.values()) == 450 and outcomes["error"] > 50 and outcomes["ok"] > 10, outcomes
+
+
 def test_loader_is_the_default_reader_unless_enabled(monkeypatch):
     from premvos_amd import jpeg
     monkeypatch.delenv("PREMVOS_GPU_JPEG", raising=False)

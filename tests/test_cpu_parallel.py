@@ -127,3 +127,141 @@ def test_result_exchange_layout_is_fixed_size_and_bit_packed():
     assert x.flow_bytes == 16 * 480 * 854 * 2 * 4 and x.mask_bytes == 16 * 20 * 480 * 854 // 8
     assert x.off_small % 16 == 0 and x.nbytes == x.off_small + 16 * (2 * 20 * 5 + 2 + 20) * 4
     assert x.nbytes < 0.16 * (x.flow_bytes + 16 * 20 * 480 * 854 + 16 * 222 * 4) + x.flow_bytes      # masks shrink 8x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the product's sharding (premvos_amd.stream.run -> parallel.plan_shards + stream.iter_chunks)
+def test_plan_shards_whole_videos_and_chunk_aligned_ranges():
+    # at least as many videos as ranks: whole videos, balanced by frame count (or the reference's contiguous slices)
+    counts = [70, 50, 30, 90, 20]
+    plans = [P.plan_shards(counts, 3, r, 8) for r in range(3)]
+    assert sorted(x for p in plans for x in p) == [(v, 0, n) for v, n in enumerate(counts)]
+    assert max(sum(e - s for _, s, e in p) for p in plans) == 90            # 90 | 70+20 | 50+30
+    assert [P.plan_shards(counts, 2, r, 8, "contiguous") for r in range(2)] == [[(0, 0, 70), (1, 0, 50), (2, 0, 30)],
+                                                                              [(3, 0, 90), (4, 0, 20)]]
+    # fewer videos than ranks: every video is cut at multiples of the chunk; the ranges tile [0, n) without gaps or overlaps
+    for world in (2, 3, 8, 11):
+        for counts in ([70, 50], [7], [1], [16, 0, 3]):
+            plans = [P.plan_shards(counts, world, r, 8) for r in range(world)] if len(counts) < world else None
+            if plans is None:
+                continue
+            for v, n in enumerate(counts):
+                rs = sorted((s, e) for p in plans for vv, s, e in p if vv == v)
+                assert all(s % 8 == 0 for s, _ in rs) and all(e % 8 == 0 or e == n for _, e in rs)
+                assert [s for s, _ in rs] == [0] * bool(rs) + [e for _, e in rs][:-1] and (not rs or rs[-1][1] == n)
+                assert bool(rs) == (n > 0)
+    # the extra chunk does not always land on the first ranks: 2 videos of 9 chunks over 8 ranks
+    plans = [P.plan_shards([72, 72], 8, r, 8) for r in range(8)]
+    assert sorted(sum(e - s for _, s, e in p) for p in plans) == [16] * 6 + [24] * 2
+    with pytest.raises(ValueError):
+        P.plan_shards([5], 2, 2, 8)
+
+
+def _shard_worker(rank, world, port, q, n_frames, batch):
+    """Every rank walks ITS shards with the product's chunk iterator and a fake decoder (frame = its index); the 'stages' are
+    what the real ones do with a chunk: one proposal result per owned frame, one flow pair per (frame, successor)."""
+    import numpy as np
+    from premvos_amd import stream
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    images = [f"/video/{t:05d}.jpg" for t in range(n_frames)]
+    decoded = []
+
+    def load(fn):
+        decoded.append(fn)
+        return np.full((2, 2, 3), int(os.path.basename(fn)[:5]), dtype=np.int32)
+    owned, pairs, chunk_sizes = [], [], []
+    for _, first, end in P.plan_shards([n_frames], world, rank, batch):
+        for names, frames, nxt in stream.iter_chunks(images, first, end, batch, load):
+            ids = [int(f[0, 0, 0]) for f in frames]
+            assert [int(n) for n in names] == ids
+            owned += ids
+            chunk_sizes.append(len(ids))
+            second = ids[1:] + ([int(nxt[0, 0, 0])] if nxt is not None else [])
+            pairs += list(zip(ids, second))
+    assert len(decoded) == len(set(decoded))                                   # every frame decoded once per rank
+    res = torch.tensor([[a, b] for a, b in pairs] or [[-1, -1]], dtype=torch.int64)
+    got = P.gather_padded(res, len(pairs), P.max_shard(-(-n_frames // batch), world) * batch)
+    own = [None] * world
+    dist.all_gather_object(own, (owned, chunk_sizes, len(decoded)))
+    if rank == 0:
+        q.put(([g.tolist() for g in got], own))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch,world", [(7, 2, 2), (16, 4, 2), (5, 8, 2)])
+def test_frame_range_sharding_with_boundary_frames_world2_gloo(n_frames, batch, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q, n_frames, batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    pairs, own = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # every frame is owned by exactly one rank; every pair (t, t+1) is computed exactly once, the boundary ones included
+    assert sorted(t for o, _, _ in own for t in o) == list(range(n_frames))
+    assert sorted(tuple(x) for g in pairs for x in g) == [(t, t + 1) for t in range(n_frames - 1)]
+    # the chunks are the ones a single rank forms (cuts at multiples of the batch): same launch shapes whatever the world size
+    assert sorted(c for _, cs, _ in own for c in cs) == sorted([batch] * (n_frames // batch) + [n_frames % batch] * bool(n_frames % batch))
+    # a rank whose range stops inside the video decodes exactly one frame more than it owns
+    for r, (o, _, ndec) in enumerate(own):
+        assert ndec == len(o) + (1 if o and o[-1] != n_frames - 1 else 0)
+
+
+def _async_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, P_, H, W = 2, 3, 5, 7
+    x = P.ResultExchange(B, H, W, P_, "cpu", pack_bits=_np_pack_bits, unpack_bits=_np_unpack_bits)
+    ok, slots = True, []
+    for step in range(5):                   # double-buffered: the gather of step i is waited for when slot i % 2 comes round again
+        slots.append(x.exchange_async(_fake_results(10 * step + rank, B, P_, H, W)))
+        if step >= 1 and rank == 0:         # "one step later": the previous step's buffers are complete and untouched by this step
+            x.wait(slots[step - 1])
+            for r in range(world):
+                ref, u = _fake_results(10 * (step - 1) + r, B, P_, H, W), x.unpack(x.gathered_slot(slots[step - 1])[r])
+                ok = ok and all(torch.equal(u[k], ref[k]) for k in ref)
+    x.flush()
+    if rank == 0:
+        q.put(ok and slots == [0, 1, 0, 1, 0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_exchange_async_double_buffered_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_async_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120) is True
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+
+def test_stage_drivers_take_the_reference_slice_of_the_video_list(monkeypatch):
+    """`torch.distributed.run -m premvos_amd.<stage>.driver`: rank r works on the r-th contiguous slice of the video list
+    (curr_run_num / total_to_run of DAVISFewShotSegmentationDataset.py:130-150), all of it outside the launcher."""
+    vids = [f"v{i}" for i in range(7)]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert P.my_videos(vids) == vids and P.env_rank() == (1, 0, 0)
+    got = []
+    for r in range(3):
+        monkeypatch.setenv("WORLD_SIZE", "3")
+        monkeypatch.setenv("RANK", str(r))
+        monkeypatch.setenv("LOCAL_RANK", str(r))
+        got.append(P.my_videos(vids))
+    assert got == [vids[0:3], vids[3:5], vids[5:7]] and P.env_rank() == (3, 2, 2)

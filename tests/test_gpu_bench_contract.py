@@ -26,7 +26,7 @@ def _run(extra_env, *args):
 def test_bench_line_through_the_distributed_path():
     d = _run({"PREMVOS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
               "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
-             "--no-cpu-baseline")
+             "--scaling", "weak", "--no-cpu-baseline")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -48,13 +48,31 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update({"PREMVOS_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PREMVOS_AUTOTUNE": "0"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch",
-                        "2", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env, timeout=1500)
+                        "2", "--scaling", "weak", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_step_per_gpu"] == 2
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_launch_per_gpu"] == 2 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 2 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]      # whole-job frames / max-over-ranks time
+
+
+def test_bench_strong_scaling_shards_one_video_over_two_ranks():
+    """The default mode: ONE synthetic video shared out by premvos_amd.parallel.plan_shards -- 7 frame pairs in chunks of 2 over
+    two ranks = ranges [0,4) and [4,7): rank 0 reads frame 4 as the second image of its last pair, rank 1's last chunk is ragged
+    (one frame, padded to the launch batch, counted once).  value = frames of the video / max-over-ranks time per pass."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"PREMVOS_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch",
+                        "2", "--frames", "7", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env,
+                       timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_step"] == 7
+    assert abs(d["value"] - 7 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert d["conv_configurations"]["signatures_explored_by_time"] == 0                   # nothing was chosen by wall clock
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -40,17 +40,21 @@ def _harness():
     return mod
 
 
-def _make_tree(root, h=120, w=200, t=3):
+def _make_tree(root, h=120, w=200, t=3, videos=None):
+    """``videos``: {name: frames}; default one clip 'bear' of ``t`` frames (its decoded frames are returned)."""
     from PIL import Image
-    seq_dir = root / "data" / "DAVIS" / "JPEGImages" / "480p" / "bear"
-    seq_dir.mkdir(parents=True)
+    videos = videos or {"bear": t}
     frames = []
-    for i in range(t):
-        pair = O.synth_frame_pair(h, w + (-w) % 8, seed=40, shift=(1.5 * i, -0.5 * i))
-        img = (pair[0, 3:, :, :w].permute(1, 2, 0) * 255).round().to(torch.uint8).numpy()
-        Image.fromarray(img).save(seq_dir / f"{i:05d}.jpg", quality=95)
-        frames.append(np.asarray(Image.open(seq_dir / f"{i:05d}.jpg").convert("RGB")))
-    (root / "seq_to_run.txt").write_text("data/DAVIS/JPEGImages/480p/bear/\n")
+    for vi, (name, nt) in enumerate(videos.items()):
+        seq_dir = root / "data" / "DAVIS" / "JPEGImages" / "480p" / name
+        seq_dir.mkdir(parents=True)
+        for i in range(nt):
+            pair = O.synth_frame_pair(h, w + (-w) % 8, seed=40 + vi, shift=(1.5 * i, -0.5 * i))
+            img = (pair[0, 3:, :, :w].permute(1, 2, 0) * 255).round().to(torch.uint8).numpy()
+            Image.fromarray(img).save(seq_dir / f"{i:05d}.jpg", quality=95)
+            if vi == 0:
+                frames.append(np.asarray(Image.open(seq_dir / f"{i:05d}.jpg").convert("RGB")))
+    (root / "seq_to_run.txt").write_text("".join(f"data/DAVIS/JPEGImages/480p/{name}/\n" for name in videos))
     wd = root / "weights"
     wd.mkdir()
     torch.save({"state_dict": O.synth_state_dict(0)}, wd / "pwc.pth.tar")
@@ -235,6 +239,67 @@ def test_streaming_driver_writes_the_stage_drivers_tree(tmp_path, monkeypatch):
     assert fa == fb and len(fa) == 4 + 4 * 5
     for f in fa:
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
+
+
+def _stream_subprocess(root, *extra, gpus=1):
+    """A FRESH process (or two ranks of them, sharing the test box's one GPU over gloo -- RCCL needs a device per rank)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"PREMVOS_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PYTHONPATH": repo})
+    r = subprocess.run([sys.executable, "-m", "premvos_amd.stream", "--root", str(root), "--gpus", str(gpus), "--flow_weights",
+                        "weights/pwc.pth.tar", "--general_weights", "weights/proposal_general_weights", "--specific_weights",
+                        "weights/specific.pt", "--refinement_weights", "weights/refinement_specific_weights", *extra],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=repo)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return r.stdout
+
+
+def _same_tree(a, b, n_files):
+    fa = sorted(str(p.relative_to(a)) for p in a.rglob("*") if p.is_file())
+    fb = sorted(str(p.relative_to(b)) for p in b.rglob("*") if p.is_file())
+    assert fa == fb and len(fa) == n_files, (len(fa), len(fb))
+    for f in fa:
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+
+
+def test_two_ranks_write_the_one_rank_tree_whole_videos(tmp_path):
+    """`python -m premvos_amd.stream --gpus 2` on a 7-frame, 2-video tree (one whole video per rank,
+    premvos_amd.parallel.plan_shards) writes the byte-identical output tree of the 1-rank run -- both in fresh processes, so this
+    is also the run-to-run reproducibility check (the conv configurations come from the shipped table or the
+    closed-form rule, never from a stopwatch race between kernels that round differently)."""
+    roots = []
+    for tag, gpus in (("one", 1), ("two", 2)):
+        root = tmp_path / tag
+        root.mkdir()
+        _make_tree(root, videos={"bear": 4, "camel": 3})
+        out = _stream_subprocess(root, "--batch", "2", gpus=gpus)
+        assert "frames: 7" in out
+        roots.append(root / "output")
+    _same_tree(roots[0] / "intermediate", roots[1] / "intermediate", (3 + 2) + 4 * 7)
+    m1, m2 = (json.load(open(r / "premvos_amd_manifest.json")) for r in roots)
+    assert m1["ranks"] == 1 and m2["ranks"] == 2 and m2["frames"] == 7
+    assert sorted(len(p) for p in m2["shards"]) == [1, 1]                                   # one whole video per rank
+    assert m1["conv_configurations"] == m2["conv_configurations"]                           # same table, same rule count
+    assert m1["conv_configurations"]["signatures_explored_by_time"] == 0
+
+
+def test_two_ranks_write_the_one_rank_tree_frame_ranges(tmp_path):
+    """Fewer videos than ranks: ONE 7-frame video in chunks of 2 -> rank 0 owns frames [0,4) and reads frame 4 as the second
+    image of its last flow pair, rank 1 owns [4,7).  Same bytes as the 1-rank run, with per-rank writers and with --gather
+    (every file handed to rank 0 in one padded gather per shard item)."""
+    roots = []
+    for tag, gpus, extra in (("one", 1, ()), ("two", 2, ()), ("gathered", 2, ("--gather",))):
+        root = tmp_path / tag
+        root.mkdir()
+        _make_tree(root, t=7)
+        _stream_subprocess(root, "--batch", "2", *extra, gpus=gpus)
+        roots.append(root / "output")
+    for other in roots[1:]:
+        _same_tree(roots[0] / "intermediate", other / "intermediate", 6 + 4 * 7)
+    m = json.load(open(roots[1] / "premvos_amd_manifest.json"))
+    assert sorted((a, b) for p in m["shards"] for _, a, b in p) == [(0, 4), (4, 7)]
 
 
 def test_binary_side_car_holds_what_the_json_holds(tmp_path):
