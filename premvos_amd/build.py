@@ -8,7 +8,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(CSRC, "libpremvos_hip.so")
+# PREMVOS_LIB_PATH: developer A/B runs load another build of the library (tools/dev/ab_build.sh); never set in production
+LIB = os.environ.get("PREMVOS_LIB_PATH") or os.path.join(CSRC, "libpremvos_hip.so")
 ARCH = "gfx950"
 
 
@@ -36,6 +37,8 @@ def _file_flags(src: str) -> "list[str]":
 
 
 def needs_build() -> bool:
+    if os.environ.get("PREMVOS_LIB_PATH"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

@@ -20,6 +20,7 @@
 //
 // Reference call sites replaced: see include/premvos_hip.h (premvos_conv2d_f32).
 #include "common.h"
+#include <type_traits>
 
 namespace premvos {
 thread_local char g_err[512] = "";
@@ -42,7 +43,7 @@ constexpr int BK = 16;           // k granularity of the packed weights (k_pad %
 // the per-stage tap bookkeeping and 64-bit address arithmetic of the general path drop out (most ResNet / Xception
 // layers; the scalar+vector work between the barrier and the first MFMA of a stage was ~15 % of a stage).
 template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16, bool PW = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
+__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) ? 3 : 1) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
@@ -177,34 +178,63 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_f32_kernel(const prem
   lstore(0);
   __syncthreads();
 
+  // Padding that is never multiplied (round 3).  (1) Columns: a wave whose 32-column blocks lie (partly) beyond cout -- the last
+  // column tile of the 728-wide Xception layers holds 88 real columns of 128 -- skips the MFMAs and B-fragment reads of its
+  // empty blocks; the matrix pipe is shared by the waves of the 3 workgroups resident on a CU, so the freed slots go to them.
+  // (2) K: the last stage of a matrix whose K is not a multiple of the stage depth (728 = 45.5 x 16) only runs the 8-deep groups
+  // that hold real k.  Both skip products with an all-zero operand: same sums (up to the sign of an exact zero).
+#ifdef PV_DBG_NOSKIP           // developer A/B builds (tools/dev/ab_build.sh): multiply the padding like rounds 1-2 did
+  const int nvalid = NTL, h_last = KB / 8;
+#else
+  const int nvalid = min(NTL, max(0, (p.cout - (n0 + wn0) + 31) / 32));           // wave-uniform
+  const int kreal = p.kh * p.kw * p.cin_pad;
+  const int h_last = min(KB / 8, max(1, (kreal - (KT_all - 1) * KB + 7) / 8));    // 8-deep groups of the matrix's last stage
+#endif
+
   const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) gload(kt_begin + kt + 1);
-    const float* a = &lds[buf][wm0 * RS + frag_off];
-    const float* b = &lds[buf][(BM + wn0) * RS + frag_off];
+  // One straight-line copy of the K loop per number of live column blocks (no per-block condition inside it: conditional
+  // accumulator updates cost the kernel 45 VGPRs and a wave per SIMD when they were tried); the last stage is peeled so that
+  // only it carries the run-time bound on its 8-deep groups.
+  auto k_loop = [&](auto nv_tag) {
+    constexpr int NV = decltype(nv_tag)::value;
+    auto compute = [&](const float* a, const float* b, const int hcnt) {
 #pragma unroll
-    for (int h = 0; h < KB / 8; ++h) {
-      float4 af[MT], bf[NTL];
+      for (int h = 0; h < KB / 8; ++h) {
+        if (h >= hcnt) break;                  // (folds away where hcnt is the constant KB / 8)
+        float4 af[MT], bf[NV > 0 ? NV : 1];
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
+        for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS + h * 8);
 #pragma unroll
-      for (int ni = 0; ni < NTL; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
-      // four k-steps in a row on ONE accumulator (dependent MFMAs issue back to back at the pipe's own 64-cycle pace; measured:
-      // walking the accumulators round-robin instead is 1.5 % slower)
+        for (int ni = 0; ni < NV; ++ni) bf[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS + h * 8);
+        // four k-steps in a row on ONE accumulator (dependent MFMAs issue back to back at the pipe's own 64-cycle pace;
+        // measured: walking the accumulators round-robin instead is 1.5 % slower)
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NTL; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
-        }
+          for (int ni = 0; ni < NV; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+          }
+      }
+    };
+    const bool ends_matrix = kt_end == KT_all;       // this workgroup's last stage is the matrix's last stage
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+      const int buf = kt & 1;
+      gload(kt_begin + kt + 1);
+      compute(&lds[buf][wm0 * RS + frag_off], &lds[buf][(BM + wn0) * RS + frag_off], KB / 8);
+      lstore(buf ^ 1);
+      __syncthreads();
     }
-    if (kt + 1 < KT) lstore(buf ^ 1);
+    const int buf = (KT - 1) & 1;
+    compute(&lds[buf][wm0 * RS + frag_off], &lds[buf][(BM + wn0) * RS + frag_off], ends_matrix ? h_last : KB / 8);
     __syncthreads();
-  }
+  };
+  if (nvalid == NTL) k_loop(std::integral_constant<int, NTL>{});
+  else if (NTL > 2 && nvalid == 2) k_loop(std::integral_constant<int, (NTL > 2 ? 2 : 0)>{});
+  else if (NTL > 1 && nvalid == 1) k_loop(std::integral_constant<int, (NTL > 1 ? 1 : 0)>{});
+  else k_loop(std::integral_constant<int, 0>{});
 
   if constexpr (SPLITK) {   // raw partial slab, ncols = gridDim.y * BN (padded: no column predicate needed)
     const int ncols = gridDim.y * BN;
