@@ -61,6 +61,9 @@ def parse():
                     help="strong scaling: frame pairs of the video (default 16 chunks = 16 x --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--file-to-file", type=int, default=int(os.environ.get("PREMVOS_BENCH_F2F_FRAMES", "128")), metavar="FRAMES",
+                    help="after the timed region (N = 1, 480p): also measure JPEG-in -> files-out through premvos_amd.stream on this "
+                         "many synthetic frames (0 = skip; the result is the `file_to_file` object of the JSON line)")
     return ap.parse_args()
 
 
@@ -123,6 +126,51 @@ def cpu_baseline():
                       f"1 proposal_net pass @749x1333/100 RoIs ({t_prop:.2f} s), 1 refinement box @385x385 ({t_box:.2f} s), "
                       f"fp32 oracle/*.py on torch {torch.__version__} CPU with {cores} of {ncpu} host threads; scaled to a frame "
                       f"as flow + 2*proposal + {P_BOXES}*box = {per_frame:.1f} s"}
+
+
+def file_to_file(n_frames: int, chunk: int):
+    """Secondary measurement, FILE TO FILE: a synthetic 480p JPEG sequence through premvos_amd.stream (one process, this GPU):
+    JPEG decode, the four stages, .flo / proposal JSON / combined JSON / refined JSON with COCO-RLE strings on disk -- the
+    reference's stage interface.  One cold run (plans are built), then the best of two warm runs."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    from premvos_amd import stream, synth
+    root = tempfile.mkdtemp(prefix="premvos_f2f_")
+    try:
+        seq = os.path.join(root, "data", "DAVIS", "JPEGImages", "480p", "clip")
+        os.makedirs(seq)
+        for s0 in range(0, n_frames, 32):
+            fr = synth.clip_frames(s0, min(s0 + 32, n_frames), 480, 854).numpy()
+            for i, im in enumerate(fr):
+                Image.fromarray(im).save(os.path.join(seq, f"{s0 + i:05d}.jpg"), quality=95)
+        wd = os.path.join(root, "weights")
+        os.makedirs(wd)
+        torch.save({"state_dict": synth.pwc_state_dict(0)}, os.path.join(wd, "pwc.pth.tar"))
+        torch.save(synth.proposal_weights(0), os.path.join(wd, "general.pt"))
+        torch.save(synth.proposal_weights(1), os.path.join(wd, "specific.pt"))
+        torch.save(synth.refinement_weights(0), os.path.join(wd, "refine.pt"))
+        out = os.path.join(root, "output", "intermediate")
+        sp = stream.StreamPipeline(os.path.join(wd, "pwc.pth.tar"), os.path.join(wd, "general.pt"), os.path.join(wd, "specific.pt"),
+                                   os.path.join(wd, "refine.pt"), batch=chunk, out=out)
+        times = []
+        for rep in range(3):
+            shutil.rmtree(os.path.join(root, "output"), ignore_errors=True)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            n = sp.run_sequences([seq + "/"])
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t)
+        assert n == n_frames
+        props = sum(len(json.load(open(os.path.join(out, "combined_proposals", "clip", f"{i:05d}.json")))) for i in range(n_frames))
+        files = sum(len(fs) for _, _, fs in os.walk(out))
+        return {"streaming_driver_fps": round(n_frames / min(times[1:]), 2), "cold_run_s": round(times[0], 1),
+                "warm_runs_s": [round(t, 2) for t in times[1:]], "frames": n_frames, "chunk": chunk,
+                "proposals_per_frame": round(props / n_frames, 1), "files_written": files, "n_gpus": 1, "measured_by_this_run": True,
+                "what": "python -m premvos_amd.stream's pipeline object on a synthetic 480x854 JPEG sequence (quality 95): decode -> flow + "
+                        "proposals x2 + combine + refinement -> .flo / JSON / COCO-RLE files; `value` above stays the HBM-resident metric"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def roofline(pipe, batch):
@@ -382,23 +430,17 @@ def main():
                                   f"({xchg.nbytes if xchg else 0} B: flow f32, masks bit-packed, boxes/scores/conf) to rank 0"},
     }
     if rank == 0:
-        # secondary, profile-sourced: the same path measured FILE TO FILE (JPEG decode, .flo / JSON / COCO-RLE writing included) by
-        # tools/time_drivers.py on a GPU box earlier in the round -- `value` above is the HBM-resident metric, never this
-        import glob
-        ftf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_file_to_file.json")))
-        if ftf and a.frame == "480p":
-            try:
-                f2f = json.load(open(ftf[-1]))
-                out["file_to_file"] = {"streaming_driver_fps": f2f["streaming_driver_fps"],
-                                       "stage_drivers_one_after_the_other_fps": f2f["stage_drivers_one_after_the_other_fps"],
-                                       "frames": f2f["frames"], "proposals_per_frame": f2f["proposals_per_frame"], "n_gpus": 1,
-                                       "source": "profiles/" + os.path.basename(ftf[-1]) + " (tools/time_drivers.py; not measured by this run)"}
-            except Exception:
-                pass
         from premvos_amd import ops
         out["conv_configurations"] = ops.tune_info()     # which table / rule froze the kernels (reproducibility)
         if not a.no_roofline:
             out["roofline"] = roofline(pipe, B)
+        # secondary: the same path measured FILE TO FILE (JPEG decode, .flo / JSON / COCO-RLE writing included) by the streaming
+        # driver -- by THIS run at N = 1, after the timed region; `value` above is the HBM-resident metric, never this
+        if world == 1 and a.frame == "480p" and a.file_to_file > 0 and prec == "fp32":
+            try:
+                out["file_to_file"] = file_to_file(a.file_to_file, int(os.environ.get("PREMVOS_STREAM_BATCH", "8")))
+            except Exception as e:           # noqa: BLE001 -- a secondary leg must not take the contract line down
+                out["file_to_file"] = {"error": f"{type(e).__name__}: {e}"[:300], "measured_by_this_run": False}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -78,6 +78,8 @@ def lanes(items: Iterable[A], work: Callable[[int, A], B], n: int = None) -> Ite
 class Writer:
     """Runs ``fn(*args)`` calls on one background thread in submission order; ``close()`` waits and re-raises the first error."""
 
+    runs_callables = True                        # submit(fn) with no file argument is fine: any host work may be queued here
+
     def __init__(self, enabled: bool = True, depth: int = 64):
         self._q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._err = None

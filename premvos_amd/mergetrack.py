@@ -83,8 +83,10 @@ def mask_iou(dt: ArrayLike, gt: ArrayLike) -> np.ndarray:
     return np.where(i > 0, i / np.where(i > 0, u, 1.0), 0.0)
 
 
-def encode_masks(masks: ArrayLike) -> List[Dict[str, object]]:
-    """COCO RLE of every mask ({"size": [h, w], "counts": str}); run boundaries are found on the GPU."""
+def encode_masks_begin(masks: ArrayLike):
+    """First half of ``encode_masks``: the run boundaries of every mask are found on the GPU and copied to the host (a few
+    hundred integers per mask).  Returns a handle for ``encode_masks_finish``, which needs neither the GPU nor the masks any
+    more -- the drivers run it on the file-writer thread (FewShotSegmentationForwarder.py:140-141 does the whole encode inline)."""
     _lib.require_gpu()
     m = _dev_masks(masks)
     n, h, w = m.shape
@@ -97,15 +99,25 @@ def encode_masks(masks: ArrayLike) -> List[Dict[str, object]]:
         _lib.check(lib.premvos_rle_boundaries_u8(m.data_ptr(), n, h, w, pos.data_ptr(), cap, nruns.data_ptr(),
                                                  ws.data_ptr(), _lib.current_stream()), "rle_boundaries")
         cnt = nruns.cpu().numpy()
-        if int(cnt.max()) <= cap:
+        if n == 0 or int(cnt.max()) <= cap:
             break
         cap = int(cnt.max())                      # a very ragged mask: one retry with the exact capacity
-    posh = pos.cpu().numpy()
+    width = int(cnt.max()) if n else 0            # only the columns that hold boundaries cross PCIe
+    return pos[:, :max(width, 1)].cpu().numpy(), cnt, int(h), int(w)
+
+
+def encode_masks_finish(handle) -> List[Dict[str, object]]:
+    posh, cnt, h, w = handle
     out = []
-    for i in range(n):
+    for i in range(len(cnt)):
         edges = np.concatenate([[0], posh[i, :cnt[i]].astype(np.int64), [h * w]])
-        out.append({"size": [int(h), int(w)], "counts": rle.counts_to_string(np.diff(edges))})
+        out.append({"size": [h, w], "counts": rle.counts_to_string(np.diff(edges))})
     return out
+
+
+def encode_masks(masks: ArrayLike) -> List[Dict[str, object]]:
+    """COCO RLE of every mask ({"size": [h, w], "counts": str}); run boundaries are found on the GPU."""
+    return encode_masks_finish(encode_masks_begin(masks))
 
 
 def warp_proposals(proposals: Sequence[Dict], optflow: Union[str, ArrayLike], device_masks: bool = False) -> List[Dict]:

@@ -483,6 +483,26 @@ def autotune(descs, device="cuda", reps: int = 4):
     mode = os.environ.get("PREMVOS_AUTOTUNE", "1")
     if mode == "0" or not torch.cuda.is_available():
         return
+    force = os.environ.get("PREMVOS_FORCE_KERNEL")          # diagnostics (tests/test_gpu_error_budget.py): every layer that CAN
+    if force:                                                # run on this family does, whatever the table says
+        fam = {"igemm": 0, "direct": 1, "wino": 2, "wino_fused": 3, "wino4": 4}[force]
+        rest = []
+        for d in descs:
+            cands = [c for c in _candidates(d) if (c[0] if c[0] < 16 else 0) == fam and c[2] <= 0 and c[3] == 0]
+            if cands and fam != 0:
+                d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = cands[0]
+            else:
+                rest.append(d)
+        descs = rest
+        if fam == 0:                                         # "igemm": the closed-form implicit-GEMM choice, Winograd never
+            for d in descs:
+                c = rule_choice(d)
+                if c[0] in (2, 3, 4):
+                    w2, w4, d.wgt_wino, d.wgt_wino4 = d.wgt_wino, d.wgt_wino4, None, None
+                    c = rule_choice(d)
+                    d.wgt_wino, d.wgt_wino4 = w2, w4
+                d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = c
+            return
     with BUILD_LOCK:
         _load_default_table()
         lib = _lib.load()

@@ -188,40 +188,45 @@ class RefinementEngine:
         self.valid_data = _FeedData()
         self.trainer = _FeedTrainer(self)
 
-    def refine_frames(self, images, proposal_lists, lane: int = 0, sidecar: bool = False):
-        """Several frames of equal size at once: the crops of all of them form one batch (``RefinementNet.refine_group``).
+    def refine_frames(self, images, proposal_lists, lane: int = 0, sidecar: bool = False, defer: bool = False):
+        """Several frames of equal size at once: the crops of all of them form one batch, PACKED (``RefinementNet.refine_packed``:
+        sum(n_i) slots rounded up to the next bucket, not frames x max(n_i)).
         ``lane`` selects an independent workspace of the net, so calls on different lanes may run concurrently (each on the
         calling thread's current stream).  ``sidecar``: instead of "segmentation" (COCO RLE) / "conf_score" (str) the proposals get
-        "mask_bits" (packed on the GPU, premvos_amd.sidecar layout) and "conf" (float32) -- the optional binary fast path."""
+        "mask_bits" (packed on the GPU, premvos_amd.sidecar layout) and "conf" (float32) -- the optional binary fast path.
+        ``defer``: the GPU work and the device-to-host copies happen here, the host-side packing of the RLE strings is returned
+        as a callable (run it on another thread, e.g. the file writer's: it fills the proposal dicts); None when nothing is left."""
         live = [(im, pr) for im, pr in zip(images, proposal_lists) if pr]
         if not live:
-            return proposal_lists
+            return None if defer else proposal_lists
         if len(live) == 1 or max(len(pr) for _, pr in live) > self.max_boxes:
             for im, pr in live:
                 self.refine_frame(im, pr, lane=lane, sidecar=sidecar)
-            return proposal_lists
-        P = _bucket(max(len(pr) for _, pr in live))
-        boxes = np.zeros((len(live), P, 4), np.float32)
-        for g, (_, pr) in enumerate(live):
-            boxes[g, :len(pr)] = _boxes_from_proposals(pr)
+            return None if defer else proposal_lists
+        total = sum(len(pr) for _, pr in live)
+        boxes = [_boxes_from_proposals(pr) for _, pr in live]
         frames = jpeg.stack_frames([im for im, _ in live], self.net.device)
-        counts = torch.tensor([len(pr) for _, pr in live], dtype=torch.int32, device=self.net.device)
-        p = self.net.refine_group(frames, torch.from_numpy(boxes).to(self.net.device), counts, lane=lane)
-        # only the valid slots of every frame are encoded (padded slots of short frames hold empty masks)
-        valid = torch.tensor([g * P + i for g, (_, pr) in enumerate(live) for i in range(len(pr))], dtype=torch.int64,
-                             device=self.net.device)
-        sel = p.mask_g.view(-1, *p.mask_g.shape[2:]).index_select(0, valid)
-        segs = _pack_on_gpu(sel) if sidecar else _encode_on_gpu(sel)                       # run boundaries / bit packing on the GPU
-        conf = p.conf_g.cpu().numpy()
-        k = 0
-        for g, (_, pr) in enumerate(live):
-            for i in range(len(pr)):
-                if sidecar:
-                    pr[i]["mask_bits"], pr[i]["conf"] = segs[k], conf[g, i]
-                else:
-                    pr[i]["segmentation"] = segs[k]
-                    pr[i]["conf_score"] = str(conf[g, i])
-                k += 1
+        group = max(len(live), int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
+        p = self.net.refine_packed(frames, [torch.from_numpy(b) for b in boxes], _bucket_total(total), group, lane=lane)
+        sel = p.mask_g[0, :total]                                                          # the slots are contiguous: no gather
+        conf = p.conf_g[0, :total].cpu().numpy()
+        flat = [pr[i] for _, pr in live for i in range(len(pr))]
+        if sidecar:
+            segs = _pack_on_gpu(sel)
+            for k, q in enumerate(flat):
+                q["mask_bits"], q["conf"] = segs[k], conf[k]
+            return None if defer else proposal_lists
+        from ..mergetrack import encode_masks_begin, encode_masks_finish
+        handle = encode_masks_begin(sel)                                                   # run boundaries on the GPU + their D2H copy
+
+        def finish():
+            segs = encode_masks_finish(handle)                                             # differencing + ASCII packing (host only)
+            for k, q in enumerate(flat):
+                q["segmentation"] = segs[k]
+                q["conf_score"] = str(conf[k])
+        if defer:
+            return finish
+        finish()
         return proposal_lists
 
     def refine_boxes(self, frame_u8: np.ndarray, boxes_y0x0y1x1: np.ndarray):
@@ -293,6 +298,11 @@ def _bucket(n: int) -> int:
     return n
 
 
+def _bucket_total(n: int) -> int:
+    """Slots of a packed group plan: the per-frame steps up to 40, then steps of 8 (one plan -- a full activation set -- per size)."""
+    return _bucket(n) if n <= 40 else (n + 7) // 8 * 8
+
+
 def do_refinement(proposals: List[dict], image_fn: str, refinement_net: RefinementEngine) -> List[dict]:
     """MergeTrack/refinement_net_functions.py:38-64."""
     from PIL import Image
@@ -358,18 +368,23 @@ def forward_directory(engine: RefinementEngine, image_input_dir: str, bb_input_d
     if n_lanes > 1:
         engine.net.use_graph = False      # lanes launch eagerly: no HIP-graph capture on one host thread while another launches
 
-    def work(lane, jobs):
+    def work(lane, jobs):                   # GPU half here; the RLE strings are packed by the writer thread (``finish``)
         if streams[lane] is None:
-            engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], sidecar=sidecar)
+            finish = engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], sidecar=sidecar, defer=True)
         else:
             with torch.cuda.stream(streams[lane]):
-                engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], lane=lane, sidecar=sidecar)
+                finish = engine.refine_frames([j[1] for j in jobs], [j[2] for j in jobs], lane=lane, sidecar=sidecar, defer=True)
                 streams[lane].synchronize()
-        return jobs
+        return jobs, finish
+
+    def write(jobs, finish):
+        if finish is not None:
+            finish()
+        (_write_sidecars if sidecar else _write_jobs)(jobs)
 
     with iop.Writer(enabled=iop.io_threads() > 0) as writer:
-        for jobs in iop.lanes(groups(), work, n_lanes):
-            writer.submit(_write_sidecars if sidecar else _write_jobs, jobs)
+        for jobs, finish in iop.lanes(groups(), work, n_lanes):
+            writer.submit(write, jobs, finish)
     return len(files)
 
 

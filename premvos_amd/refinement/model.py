@@ -71,13 +71,19 @@ class PackedDW:
 
 
 class _Plan:
-    def __init__(self, net: "RefinementNet", P: int, H: int, W: int, with_posterior: bool, frames: int = 1):
+    def __init__(self, net: "RefinementNet", P: int, H: int, W: int, with_posterior: bool, frames: int = 1,
+                 packed: bool = False):
         """One launch list for ``frames`` frames x ``P`` boxes each: the crops of all frames form ONE batch of the network
-        (bigger GEMM M -> fewer partly filled waves of tiles); crop extraction and un-cropping run per frame."""
+        (bigger GEMM M -> fewer partly filled waves of tiles); crop extraction and un-cropping run per frame.
+        ``packed``: ``P`` is the TOTAL number of box slots of up to ``frames`` frames; which slots belong to which frame is
+        set per call (``layout``: the boxes of a frame are a contiguous run), so a group of frames with 20, 23, 25 and 22
+        proposals runs 96 crops, not 4 x 26 (eager launches only: the slot offsets are launch arguments)."""
         dev, lib = net.device, _lib.load()
-        self.P, self.H, self.W, self.G = P, H, W, frames
-        G, PF = frames, P          # PF boxes per frame
-        P = G * PF                 # batch of the network body
+        self.P, self.H, self.W, self.G, self.packed = P, H, W, frames, packed
+        G = frames
+        PF = P if packed else P    # boxes per frame (packed: the whole slot range may belong to one frame)
+        P = P if packed else G * PF    # batch of the network body
+        self.layout: List[tuple] = []  # packed: (frame, first slot, boxes) of the current call
         PK, DW = net.packed, net.packed_dw
         steps: List = []
         self.flops: Dict[str, float] = {}
@@ -119,13 +125,20 @@ class _Plan:
 
         S = INPUT_SIZE
         self.frames = torch.zeros((G, H, W, 3), dtype=torch.uint8, device=dev)
-        self.boxes_g = torch.zeros((G, PF, 4), dtype=torch.float32, device=dev)       # y0 x0 y1 x1
+        NG = 1 if packed else G        # leading dimension of the per-frame result views ([1, slots, ...] when packed)
+        self.boxes_g = torch.zeros((NG, PF, 4), dtype=torch.float32, device=dev)      # y0 x0 y1 x1
         self.count = torch.zeros((G,), dtype=torch.int32, device=dev)
-        self.crops = torch.zeros((G, PF, 4), dtype=torch.int32, device=dev)
+        self.crops = torch.zeros((NG, PF, 4), dtype=torch.int32, device=dev)
         self.frame, self.boxes = self.frames[0], self.boxes_g[0]                      # single-frame views
         self.net_in = alloc(P, S, S, 4)
 
         def mk_input():
+            if packed:
+                for g, off, n in self.layout:
+                    _lib.check(lib.premvos_refine_input_u8(self.frames[g].data_ptr(), H, W, self.boxes_g[0, off:].data_ptr(),
+                                                           self.count[g:].data_ptr(), n, S, self.net_in.images(off, n).ptr,
+                                                           self.crops[0, off:].data_ptr(), _lib.current_stream()), "refine_input")
+                return
             for g in range(G):
                 _lib.check(lib.premvos_refine_input_u8(self.frames[g].data_ptr(), H, W, self.boxes_g[g].data_ptr(),
                                                        self.count[g:].data_ptr(), PF, S,
@@ -216,15 +229,23 @@ class _Plan:
         conv(d, "logits/features", self.logits)
 
         # SegmentationSoftmax eval branch + conf_score
-        self.mask_g = torch.zeros((G, PF, H, W), dtype=torch.uint8, device=dev)
-        self.posterior_g = torch.zeros((G, PF, H, W), dtype=torch.float32, device=dev) if with_posterior else None
-        self.conf_g = torch.zeros((G, PF), dtype=torch.float32, device=dev)
+        self.mask_g = torch.zeros((NG, PF, H, W), dtype=torch.uint8, device=dev)
+        self.posterior_g = torch.zeros((NG, PF, H, W), dtype=torch.float32, device=dev) if with_posterior else None
+        self.conf_g = torch.zeros((NG, PF), dtype=torch.float32, device=dev)
         self.mask, self.conf = self.mask_g[0], self.conf_g[0]                         # single-frame views
         self.posterior = self.posterior_g[0] if with_posterior else None
         wsb = int(lib.premvos_refine_output_workspace_bytes(PF, S, H, W))
         self.ws = torch.zeros((wsb + 15) // 16 * 4, dtype=torch.float32, device=dev)
 
         def out_layer(lg=self.logits):
+            if packed:
+                for g, off, n in self.layout:
+                    lgf = lg.images(off, n)
+                    _lib.check(lib.premvos_refine_output_f32(
+                        lgf.ptr, lgf.ps, lgf.h, lgf.w, self.crops[0, off:].data_ptr(), self.count[g:].data_ptr(), n, S, H, W,
+                        self.mask_g[0, off:].data_ptr(), self.posterior_g[0, off:].data_ptr() if with_posterior else None,
+                        self.conf_g[0, off:].data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
+                return
             for g in range(G):          # stream-ordered, so the frames can share the scratch buffer
                 lgf = lg.images(g * PF, PF)
                 _lib.check(lib.premvos_refine_output_f32(
@@ -282,10 +303,11 @@ class RefinementNet:
                 else:
                     self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device, precision=prec)
 
-    def plan(self, P: int, H: int, W: int, with_posterior: bool = False, lane: int = 0, frames: int = 1) -> _Plan:
+    def plan(self, P: int, H: int, W: int, with_posterior: bool = False, lane: int = 0, frames: int = 1,
+             packed: bool = False) -> _Plan:
         """``lane`` selects an independent workspace (same weights) so several calls can be in flight; ``frames`` > 1
-        builds a plan that refines that many frames (P boxes each) as one batch."""
-        key = (P, H, W, with_posterior, lane, frames)
+        builds a plan that refines that many frames (P boxes each) as one batch; ``packed``: P slots shared by <= frames frames."""
+        key = (P, H, W, with_posterior, lane, frames, packed)
         with self._plans_lock:                    # LRU: a hit moves the plan to the young end (dicts keep insertion order)
             p = self._plans.pop(key, None)
             if p is not None:
@@ -295,8 +317,8 @@ class RefinementNet:
             with self._plans_lock:                # graph capture of a plan is done by one of them at a time
                 p = self._plans.get(key)
             if p is None:
-                p = _Plan(self, P, H, W, with_posterior, frames)
-                if self.use_graph:
+                p = _Plan(self, P, H, W, with_posterior, frames, packed)
+                if self.use_graph and not packed:
                     torch.cuda.synchronize()      # capture must not race kernels of another lane's stream
                     p.capture()
                 with self._plans_lock:
@@ -326,6 +348,29 @@ class RefinementNet:
             p.graph.replay()
         else:
             p.run()
+        return p
+
+    def refine_packed(self, frames_rgb: torch.Tensor, boxes_per_frame: List[torch.Tensor], slots: int, max_frames: int,
+                      lane: int = 0) -> _Plan:
+        """Several frames at once with the boxes PACKED: frames uint8 [g,H,W,3] (g <= max_frames), ``boxes_per_frame[i]`` float
+        [n_i,4] (host or device), sum(n_i) <= ``slots``.  Results in the plan: ``mask_g[0]`` [slots,H,W], ``conf_g[0]`` [slots];
+        the boxes of frame i occupy the slots [sum(n_<i), sum(n_<=i)).  Same numbers as ``refine`` on each frame (every crop is
+        an independent batch element); the launches are eager (slot offsets are launch arguments)."""
+        g, H, W, _ = frames_rgb.shape
+        counts = [int(b.shape[0]) for b in boxes_per_frame]
+        total = sum(counts)
+        assert g == len(counts) <= max_frames and total <= slots
+        p = self.plan(slots, H, W, False, lane, frames=max_frames, packed=True)
+        p.frames[:g].copy_(frames_rgb)
+        p.boxes_g[0].zero_()
+        if total:
+            p.boxes_g[0, :total].copy_(torch.cat([torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4) for b in boxes_per_frame]))
+        cnt = torch.zeros((max_frames,), dtype=torch.int32)
+        cnt[:g] = torch.tensor(counts, dtype=torch.int32)
+        p.count.copy_(cnt)
+        offs = [sum(counts[:i]) for i in range(g)]
+        p.layout = [(i, offs[i], counts[i]) for i in range(g) if counts[i] > 0]
+        p.run()                             # (unused slots run on whatever finite crops an earlier call left there; never read)
         return p
 
     def refine_group(self, frames_rgb: torch.Tensor, boxes_y0x0y1x1: torch.Tensor, counts: Optional[torch.Tensor] = None,

@@ -79,7 +79,11 @@ class StreamPipeline:
             self.nets.append(pd.ProposalNet(w, num_blocks=pd.infer_num_blocks(w), use_graph=False))
         rw = rd.load_weights(refinement_weights)
         self.engine = rd.RefinementEngine(rd.RefinementNet(rw, rd.infer_num_middle(rw), use_graph=False))
-        self.streams = {k: torch.cuda.Stream(device=self.dev) for k in ("flow", "prop0", "prop1", "ref", "decode")}
+        # refinement is half of a frame's FLOPs and has the longest host tail (D2H of masks' run boundaries): two lanes = two host
+        # threads, each with its own stream and workspace of the net, take the chunks in turn (PREMVOS_STREAM_REFINE_LANES)
+        self.refine_lanes = max(1, int(os.environ.get("PREMVOS_STREAM_REFINE_LANES", "2")))
+        self.streams = {k: torch.cuda.Stream(device=self.dev)
+                        for k in ["flow", "prop0", "prop1", "decode"] + [f"ref{i}" for i in range(self.refine_lanes)]}
         self.flow_stages, self.prop_stages = {}, {}
 
     # ---- the stage bodies (each runs on its own host thread and HIP stream) ----------------------------------------
@@ -118,20 +122,36 @@ class StreamPipeline:
             writer.submit(_dump_json, os.path.join(self.out, sub, seq, names[k] + ".json"), lists[k])
         return chunk, lists
 
-    def _refine(self, item, writer):
+    def _refine(self, item, writer, lane: int = 0):
         (seq, names, frames, _), general, specific = item
         combined = []
         for k in range(len(frames)):
             both = general[k] + specific[k]           # combine_general_and_specific.py:33
             writer.submit(_dump_json, os.path.join(self.out, "combined_proposals", seq, names[k] + ".json"), both)
             combined.append([dict(p) for p in both])  # the refinement stage adds keys to its own copies
-        with torch.cuda.stream(self.streams["ref"]):
+        # The GPU half runs here (this lane's stream and workspace); the host half -- run-length differencing and the ASCII packing
+        # of the COCO "counts" strings, ~25 masks per frame -- is handed to the writer thread together with the JSON dump, so
+        # this thread goes straight on to the next group's launches (round 2 packed the strings here: the thread was saturated).
+        defer = getattr(writer, "runs_callables", False)
+        finishers = []
+        st = self.streams[f"ref{lane}"]
+        with torch.cuda.stream(st):
             G = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
             for s0 in range(0, len(frames), G):
-                self.engine.refine_frames(frames[s0:s0 + G], combined[s0:s0 + G])
-            self.streams["ref"].synchronize()
-        for k in range(len(frames)):
-            writer.submit(_dump_json, os.path.join(self.out, "refined_proposals", seq, names[k] + ".json"), combined[k])
+                finishers.append(self.engine.refine_frames(frames[s0:s0 + G], combined[s0:s0 + G], lane=lane, defer=defer))
+            st.synchronize()
+        paths = [os.path.join(self.out, "refined_proposals", seq, names[k] + ".json") for k in range(len(frames))]
+        if defer:
+            def finish_and_dump():
+                for f in finishers:
+                    if f is not None:
+                        f()
+                for fn, props in zip(paths, combined):
+                    _dump_json(fn, props)
+            writer.submit(finish_and_dump)
+        else:
+            for fn, props in zip(paths, combined):
+                writer.submit(_dump_json, fn, props)
         return None
 
     # ---- the driver ---------------------------------------------------------------------------------------------------
@@ -142,7 +162,7 @@ class StreamPipeline:
         own_writer = writer is None
         writer = iop.Writer(enabled=True) if own_writer else writer
         q_flow, q_g, q_s, q_rg, q_rs = (queue.Queue(maxsize=3) for _ in range(5))
-        q_join: "queue.Queue" = queue.Queue(maxsize=3)
+        q_join: "queue.Queue" = queue.Queue(maxsize=3 + self.refine_lanes)
 
         def join_props():                            # pairs the general and the specific result of the same chunk
             try:
@@ -155,13 +175,15 @@ class StreamPipeline:
                         break
                     q_join.put((a[0], a[1], b[1]))
             finally:
-                q_join.put(_END)
+                for _ in range(self.refine_lanes):   # every consumer of q_join needs its own end marker (a single one left the
+                    q_join.put(_END)                 # second refinement thread of a round-2 experiment blocked in get() for ever)
         joiner = threading.Thread(target=join_props, name="premvos-join", daemon=True)
         joiner.start()
         threads = [_stage_thread("flow", lambda c: self._flow(c, writer), q_flow, None, errors),
                    _stage_thread("prop-general", lambda c: self._proposals(0, c, writer), q_g, q_rg, errors),
-                   _stage_thread("prop-specific", lambda c: self._proposals(1, c, writer), q_s, q_rs, errors),
-                   _stage_thread("refine", lambda it: self._refine(it, writer), q_join, None, errors), joiner]
+                   _stage_thread("prop-specific", lambda c: self._proposals(1, c, writer), q_s, q_rs, errors)]
+        threads += [_stage_thread(f"refine{i}", lambda it, i=i: self._refine(it, writer, i), q_join, None, errors)
+                    for i in range(self.refine_lanes)] + [joiner]
         n_frames = 0
         if shards is None:
             shards = [(v, 0, None) for v in range(len(folders))]
@@ -268,6 +290,8 @@ class GatherWriter:
     will run the CPU-side MergeTrack -- in ONE padded gather per shard item (premvos_amd.parallel.gather_padded; RCCL over
     xGMI on GPUs, gloo in the CPU tests); the merge rank writes every rank's files.  Same bytes as the per-rank writers: the
     payloads are produced by the same functions (flo_bytes / json.dumps)."""
+
+    runs_callables = False                       # payloads must be (path, bytes): no deferred host work on this writer
 
     def __init__(self, device, dst: int = 0):
         self.files: List[tuple] = []

@@ -26,7 +26,7 @@ def _run(extra_env, *args):
 def test_bench_line_through_the_distributed_path():
     d = _run({"PREMVOS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
               "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
-             "--scaling", "weak", "--no-cpu-baseline")
+             "--scaling", "weak", "--no-cpu-baseline", "--file-to-file", "0")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -48,7 +48,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update({"PREMVOS_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PREMVOS_AUTOTUNE": "0"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch",
-                        "2", "--scaling", "weak", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env, timeout=1500)
+                        "2", "--scaling", "weak", "--no-cpu-baseline", "--no-roofline", "--file-to-file", "0"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -64,7 +64,7 @@ def test_bench_strong_scaling_shards_one_video_over_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update({"PREMVOS_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch",
-                        "2", "--frames", "7", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env,
+                        "2", "--frames", "7", "--no-cpu-baseline", "--no-roofline", "--file-to-file", "0"], capture_output=True, text=True, env=env,
                        timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -1,0 +1,131 @@
+"""The fp32 error budget at FULL depth and full size, as recorded numbers: north_star allows 1e-3 on mask
+logits and asks for bit-exact proposal indices; the conv kernels of one layer differ in rounding (implicit GEMM ~1e-6 of the
+output scale, Winograd F(2x2,3x3) ~1e-6..1e-5, F(4x4,3x3) ~1e-5), and 74 layers of a pipeline step run F(4x4,3x3).  Each test
+runs one net three times -- every layer on the implicit GEMM, the shipped configuration table, F(4x4,3x3) FORCED on every
+layer that can run it -- against the CPU oracle and writes the measured distances to gpurun_out/error_budget/<net>.json (and
+the test log); the assertions are the 1e-3 bars.  RPN indices: the strict check (GPU logits -> oracle selection == kernel
+indices) lives in tests/test_gpu_fullsize.py; here the number of the 100 indices that differ from the CPU NET's is recorded."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import proposal_oracle as PO  # noqa: E402
+from oracle import pwc_oracle as O  # noqa: E402
+from oracle import refinement_oracle as RO  # noqa: E402
+
+MODES = [("implicit_gemm_only", {"PREMVOS_FORCE_KERNEL": "igemm"}), ("shipped_table", {}),
+         ("f4x4_forced", {"PREMVOS_FORCE_KERNEL": "wino4"})]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(net, rows):
+    out = os.path.join(ROOT, "gpurun_out", "error_budget")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, net + ".json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print(f"\nerror budget, {net}:")
+    for mode, r in rows.items():
+        print("  %-20s %s" % (mode, "  ".join(f"{k}={v:.3g}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items())))
+
+
+def _families(descs):
+    fam = {}
+    for d in descs:
+        k = {1: "direct", 2: "wino2x2_slab", 3: "wino2x2_fused", 4: "wino4x4"}.get(d.tile_hint, "igemm")
+        fam[k] = fam.get(k, 0) + 1
+    return fam
+
+
+def test_flow_error_budget(monkeypatch):
+    from premvos_amd.flow import pwc_dc_net
+    sd = O.synth_state_dict(0)
+    x = O.synth_frame_pair(512, 896, seed=7, shift=(2.5, -1.25))
+    with torch.no_grad():
+        ref = O.pwc_forward(sd, x)
+    rows = {}
+    for mode, env in MODES:
+        for k in ("PREMVOS_FORCE_KERNEL",):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = pwc_dc_net(None).cuda().eval()
+        net.load_state_dict(sd)
+        got = net(x.cuda()).cpu()
+        err = float((got - ref).abs().max())
+        rows[mode] = {"flow_max_abs_err_px": err, "flow_max_abs": float(ref.abs().max()),
+                      "rel_to_bar": err / (1e-3 * max(1.0, float(ref.abs().max()))), "layers": _families(net.plan(1, 512, 896).descs)}
+        assert err < 1e-3 * max(1.0, float(ref.abs().max())), (mode, err)
+    _record("flow_512x896", rows)
+    assert rows["f4x4_forced"]["layers"].get("wino4x4", 0) >= rows["shipped_table"]["layers"].get("wino4x4", 0) > 0
+    assert rows["implicit_gemm_only"]["layers"].keys() <= {"igemm", "direct"}
+
+
+def test_proposal_error_budget(monkeypatch):
+    from oracle import cv_resize_oracle as CR
+    from premvos_amd.proposal import OfflinePredictor, ProposalNet, detect_one_image
+    w = PO.synth_weights(3)
+    img = np.random.default_rng(3).integers(0, 256, (480, 854, 3), dtype=np.uint8)
+    img = (img // 32 * 32 + np.linspace(0, 31, 854, dtype=np.uint8)[None, :, None]).astype(np.uint8)
+    nh, nw = PO.custom_resize_shape(480, 854)
+    (fb, fp, fl, fi), inter = PO.model_forward(w, CR.resize_linear_u8(img, nw, nh), intermediates=True)
+    rows = {}
+    for mode, env in MODES:
+        monkeypatch.delenv("PREMVOS_FORCE_KERNEL", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = ProposalNet(w)
+        detect_one_image(img, OfflinePredictor(net))
+        p = net.plan(1, nh, nw)
+        n = int(p.roi_count.item())
+        fm = p.featuremap.torch().cpu()
+        e_fm = float((fm - inter["featuremap"]).abs().max()) / max(1.0, float(inter["featuremap"].abs().max()))
+        rpn = p.rpn_out.buf[0].cpu().numpy()
+        lab = rpn[:, :, :15]
+        e_rpn = float(np.abs(lab - inter["rpn_logits"].numpy()).max()) / max(1.0, float(inter["rpn_logits"].abs().max()))
+        idx = p.roi_idx[0, :n].cpu().numpy()
+        common = len(np.intersect1d(idx, inter["proposal_idx"]))
+        same_order = int(np.sum(idx[:min(n, len(inter["proposal_idx"]))] == inter["proposal_idx"][:n]))
+        rows[mode] = {"featuremap_rel_err": e_fm, "rpn_logits_rel_err": e_rpn, "rois": n,
+                      "rpn_indices_shared_with_cpu_net": common, "rpn_indices_same_position": same_order,
+                      "layers": _families(p.descs)}
+        assert e_fm < 1e-3 and e_rpn < 2e-3, (mode, e_fm, e_rpn)
+        assert common >= 95, (mode, common)
+    _record("proposal_749x1333", rows)
+    assert rows["f4x4_forced"]["layers"].get("wino4x4", 0) >= rows["shipped_table"]["layers"].get("wino4x4", 0)
+
+
+def test_refinement_error_budget(monkeypatch):
+    from premvos_amd.refinement import RefinementNet
+    w = RO.synth_weights(4, 16)
+    H, W = 480, 854
+    boxes = [[100.0, 200.0, 300.0, 500.0], [0.0, 0.0, 480.0, 854.0], [400.2, 800.7, 470.0, 850.0]]
+    img = (np.random.default_rng(H).random((H, W, 3)) * 255).astype(np.uint8)
+    refs = []
+    for b in boxes:
+        x, crop = RO.make_input(img, b)
+        with torch.no_grad():
+            lg = RO.deeplab_logits(w, x)
+        refs.append((lg, crop) + RO.output_layer(lg, crop, H, W))
+    rows = {}
+    for mode, env in MODES:
+        monkeypatch.delenv("PREMVOS_FORCE_KERNEL", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = RefinementNet(w, 16)
+        p = net.refine(torch.from_numpy(img).cuda(), torch.tensor(boxes).cuda(), max_boxes=4, with_posterior=True)
+        e_lg = e_post = 0.0
+        flips = 0
+        for i, (lg, crop, rm, rp) in enumerate(refs):
+            glg = p.logits.torch().cpu()[i:i + 1]
+            e_lg = max(e_lg, float((glg - lg).abs().max()) / max(1.0, float(lg.abs().max())))
+            e_post = max(e_post, float(np.abs(p.posterior[i].cpu().numpy() - rp).max()))
+            flips += int((p.mask[i].cpu().numpy() != rm).sum())
+        rows[mode] = {"mask_logit_rel_err": e_lg, "posterior_max_abs_err": e_post, "mask_pixels_flipped_of": f"{flips}/{3 * H * W}",
+                      "layers": _families(net.plan(4, H, W, True).descs)}
+        assert e_lg < 1e-3 and e_post < 1e-3, (mode, e_lg, e_post)
+    _record("refinement_385x385", rows)

@@ -182,6 +182,49 @@ def test_refine_group_equals_per_frame_calls():
         assert int(mg[g, counts[g]:].sum()) == 0
 
 
+def test_refine_packed_equals_per_frame_calls_and_engine_defers_the_rle_strings():
+    """Round 3: the boxes of a group of frames are PACKED into sum(n_i) slots (refine_packed) instead of frames x max(n_i): same
+    masks / conf as per-frame refine() calls; and RefinementEngine.refine_frames(defer=True) -- GPU work + D2H now, RLE string
+    packing in the returned callable (the writer thread's job) -- fills the same dicts as the inline form."""
+    from premvos_amd.refinement import RefinementEngine, RefinementNet
+    nm = 1
+    net = RefinementNet(R.synth_weights(3, nm), nm)
+    rng = np.random.default_rng(11)
+    frames = torch.from_numpy(rng.integers(0, 256, (4, 100, 160, 3), dtype=np.uint8)).cuda()
+    counts = [5, 0, 2, 3]
+    per = []
+    for g in range(4):
+        b = np.zeros((counts[g], 4), np.float32)
+        for i in range(counts[g]):
+            y0, x0 = rng.uniform(0, 50), rng.uniform(0, 90)
+            b[i] = [y0, x0, y0 + rng.uniform(10, 45), x0 + rng.uniform(10, 65)]
+        per.append(torch.from_numpy(b))
+    pp = net.refine_packed(frames, per, slots=12, max_frames=4)
+    mp, cp = pp.mask_g[0].clone(), pp.conf_g[0].clone()
+    off = 0
+    for g in range(4):
+        n = counts[g]
+        if n:
+            p1 = net.refine(frames[g], per[g].cuda(), max_boxes=6, with_posterior=True)
+            assert (cp[off:off + n] - p1.conf[:n]).abs().max().item() < 1e-5
+            diff = mp[off:off + n] != p1.mask[:n]
+            assert not bool(diff.any()) or (p1.posterior[:n][diff] - 0.5).abs().max().item() < 1e-4
+        off += n
+    # the engine: packed + deferred == packed + inline, on host frames and proposal dicts (frame 1 has no proposals)
+    imgs = [f.cpu().numpy() for f in frames]
+
+    def props():
+        return [[{"bbox": [float(b[1]), float(b[0]), float(b[3] - b[1]), float(b[2] - b[0])], "score": 0.5} for b in pb.numpy()]
+                for pb in per]
+    eng = RefinementEngine(net)
+    a, b = props(), props()
+    assert eng.refine_frames(imgs, a) is a
+    fin = eng.refine_frames(imgs, b, defer=True)
+    assert callable(fin) and "segmentation" not in b[0][0]
+    fin()
+    assert a == b and all("conf_score" in q and isinstance(q["segmentation"]["counts"], str) for pr in a for q in pr) and a[1] == []
+
+
 def test_refinement_engine_json_contract(tmp_path):
     from premvos_amd import rle
     from premvos_amd.refinement import RefinementEngine, RefinementNet
