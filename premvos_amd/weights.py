@@ -36,6 +36,8 @@ _DTYPE_IDS = {np.dtype(v): k for k, v in _DTYPES.items()}
 def _varint(buf: bytes, pos: int) -> Tuple[int, int]:
     out = shift = 0
     while True:
+        if pos >= len(buf) or shift > 63:
+            raise ValueError("tensor bundle: truncated or malformed varint")
         b = buf[pos]
         pos += 1
         out |= (b & 0x7F) << shift
@@ -178,6 +180,8 @@ def snappy_decompress(buf: bytes) -> bytes:
 # --------------------------------------------------------------------------------------------------
 # SSTable
 def _read_block(data: bytes, offset: int, size: int, verify: bool = True) -> bytes:
+    if offset < 0 or size < 4 or offset + size + 5 > len(data):          # block + 1-byte type + 4-byte crc must lie inside the file
+        raise ValueError(f"tensor bundle index: block handle ({offset}, {size}) points outside the {len(data)}-byte file (truncated?)")
     raw = data[offset:offset + size]
     ctype = data[offset + size]
     if verify:
@@ -226,7 +230,7 @@ def read_table(path: str, verify: bool = True) -> Dict[bytes, bytes]:
 
 def load_tf_checkpoint(prefix: str, verify: bool = True) -> Dict[str, np.ndarray]:
     """Every variable of a TF tensor-bundle checkpoint as numpy arrays (TF layouts, TF names)."""
-    table = read_table(prefix + ".index")
+    table = read_table(prefix + ".index", verify)
     num_shards = 1
     for f, _, v in _pb_fields(table.get(b"", b"")):
         if f == 1:
@@ -240,12 +244,23 @@ def load_tf_checkpoint(prefix: str, verify: bool = True) -> Dict[str, np.ndarray
             continue
         e = _parse_entry(val)
         if e["slices"]:
-            raise ValueError(f"{key!r}: partitioned variables are not supported")
+            # a variable saved through a partitioner: its data lives under ordered-code slice keys, one per partition.  Neither
+            # tensorpack (proposal_net/train.py:655) nor the slim graph (Saver.py:33-48) of the reference partitions anything.
+            raise ValueError(f"{key!r}: the checkpoint stores this variable as partitioned slices (BundleEntryProto.slices); "
+                             f"re-save it unpartitioned -- the reference's graphs define no partitioner")
         if e["dtype"] not in _DTYPES:
             continue                                 # strings etc. (global_step is int64 and is kept)
         sid = e["shard_id"]
         if sid not in shards:
-            shards[sid] = np.memmap(f"{prefix}.data-{sid:05d}-of-{num_shards:05d}", dtype=np.uint8, mode="r")
+            fn = f"{prefix}.data-{sid:05d}-of-{num_shards:05d}"
+            if not (0 <= sid < num_shards) or not os.path.exists(fn):
+                raise FileNotFoundError(f"{key!r} lives in shard {sid} of {num_shards}, but {fn} does not exist")
+            shards[sid] = np.memmap(fn, dtype=np.uint8, mode="r")
+        if e["offset"] + e["size"] > shards[sid].shape[0]:
+            raise ValueError(f"{key!r}: bytes [{e['offset']}, {e['offset'] + e['size']}) lie beyond the end of shard {sid} (truncated file?)")
+        want = int(np.prod(e["shape"], dtype=np.int64)) * np.dtype(_DTYPES[e["dtype"]]).itemsize
+        if want != e["size"]:
+            raise ValueError(f"{key!r}: shape {e['shape']} needs {want} bytes, the entry holds {e['size']}")
         raw = np.asarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
         if verify and e["crc32c"] is not None and _mask_crc(crc32c(raw.tobytes())) != e["crc32c"]:
             raise ValueError(f"{key!r}: tensor checksum mismatch")
@@ -254,23 +269,27 @@ def load_tf_checkpoint(prefix: str, verify: bool = True) -> Dict[str, np.ndarray
 
 
 def save_tf_checkpoint(prefix: str, variables: Dict[str, np.ndarray], block_size: int = 4096,
-                       restart_interval: int = 16) -> None:
-    """Writer of the same format (single shard, no compression): used to export weights for the reference and to test
-    the reader; mirrors tensorflow BundleWriter + table::TableBuilder."""
+                       restart_interval: int = 16, num_shards: int = 1) -> None:
+    """Writer of the same format (no compression): used to export weights for the reference and to test the reader;
+    mirrors tensorflow BundleWriter + table::TableBuilder.  ``num_shards`` > 1 lays the variables out round-robin over
+    ``<prefix>.data-0000k-of-0000N`` files the way a merged multi-device save does (BundleEntryProto.shard_id, per-shard
+    offsets, BundleHeaderProto.num_shards)."""
     names = sorted(variables, key=lambda s: s.encode())
-    data = bytearray()
-    entries: List[Tuple[bytes, bytes]] = [(b"", b"\x08\x01\x10\x00\x1a\x02\x08\x01")]   # num_shards=1, LITTLE, version{producer=1}
-    for n in names:
+    data = [bytearray() for _ in range(num_shards)]
+    entries: List[Tuple[bytes, bytes]] = [(b"", b"\x08" + _put_varint(num_shards) + b"\x10\x00\x1a\x02\x08\x01")]   # LITTLE, version{producer=1}
+    for i, n in enumerate(names):
         a = np.asarray(variables[n], order="C")
         raw = a.tobytes()
+        sid = i % num_shards
         shape = b"".join(b"\x12" + _put_varint(len(d)) + d for d in (b"\x08" + _put_varint(int(s)) for s in a.shape))
-        e = (b"\x08" + _put_varint(_DTYPE_IDS[a.dtype]) + b"\x12" + _put_varint(len(shape)) + shape + b"\x18\x00" +
-             b"\x20" + _put_varint(len(data)) + b"\x28" + _put_varint(len(raw)) + b"\x35" +
+        e = (b"\x08" + _put_varint(_DTYPE_IDS[a.dtype]) + b"\x12" + _put_varint(len(shape)) + shape + b"\x18" + _put_varint(sid) +
+             b"\x20" + _put_varint(len(data[sid])) + b"\x28" + _put_varint(len(raw)) + b"\x35" +
              struct.pack("<I", _mask_crc(crc32c(raw))))
         entries.append((n.encode(), e))
-        data += raw
-    with open(f"{prefix}.data-00000-of-00001", "wb") as f:
-        f.write(bytes(data))
+        data[sid] += raw
+    for sid in range(num_shards):
+        with open(f"{prefix}.data-{sid:05d}-of-{num_shards:05d}", "wb") as f:
+            f.write(bytes(data[sid]))
 
     out = bytearray()
 

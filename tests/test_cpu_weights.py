@@ -48,6 +48,49 @@ def test_bundle_roundtrip_multi_block(tmp_path):
         W.read_table(prefix + ".index")
 
 
+def test_bundle_multi_shard_restart_points_and_damaged_files(tmp_path):
+    """What real TF-written bundles contain that the single-shard writer of round 1-2 never emitted: variables
+    spread over several ``.data-0000k-of-0000N`` shards, long runs of prefix-compressed keys between restart points (restart
+    interval 1 ... 64), and the failure modes of a download that went wrong: a missing shard, a truncated shard, a truncated or
+    bit-flipped index, an entry whose size contradicts its shape -- each an explicit error that names the variable / file."""
+    rng = np.random.default_rng(1)
+    v = {f"group{g}/block{b}/conv{c}/W": rng.standard_normal((1, 1, 8, 8)).astype(np.float32)
+         for g in range(4) for b in range(6) for c in (1, 2, 3)}
+    v.update({f"group{g}/block{b}/conv{c}/bn/mean/EMA": rng.standard_normal(8).astype(np.float32)
+              for g in range(4) for b in range(6) for c in (1, 2, 3)})
+    v["global_step"] = np.array(7, np.int64)
+    for shards, restart in ((3, 1), (2, 64), (5, 16)):
+        prefix = str(tmp_path / f"ckpt_{shards}_{restart}")
+        W.save_tf_checkpoint(prefix, v, block_size=700, restart_interval=restart, num_shards=shards)
+        assert sorted(f for f in os.listdir(tmp_path) if f.startswith(f"ckpt_{shards}_{restart}.data")) == \
+            [f"ckpt_{shards}_{restart}.data-{k:05d}-of-{shards:05d}" for k in range(shards)]
+        back = W.load_tf_checkpoint(prefix)                                  # verify=True is the default
+        assert set(back) == set(v) and all(np.array_equal(back[k], v[k]) for k in v)
+    prefix = str(tmp_path / "ckpt_3_1")
+    shard1 = prefix + ".data-00001-of-00003"
+    raw1 = open(shard1, "rb").read()
+    os.rename(shard1, shard1 + ".away")
+    with pytest.raises(FileNotFoundError, match="shard 1 of 3"):
+        W.load_tf_checkpoint(prefix)
+    open(shard1, "wb").write(raw1[:len(raw1) // 2])
+    with pytest.raises(ValueError, match="beyond the end of shard 1"):
+        W.load_tf_checkpoint(prefix)
+    flipped = bytearray(raw1)
+    flipped[5] ^= 1
+    open(shard1, "wb").write(bytes(flipped))
+    with pytest.raises(ValueError, match="tensor checksum mismatch"):
+        W.load_tf_checkpoint(prefix)
+    assert len(W.load_tf_checkpoint(prefix, verify=False)) == len(v)         # (opting out of the checksums is possible, not default)
+    open(shard1, "wb").write(raw1)
+    idx = open(prefix + ".index", "rb").read()
+    for cut in (len(idx) // 3, len(idx) - 20, 47):
+        open(prefix + ".index", "wb").write(idx[:cut] + (idx[-48:] if cut < len(idx) - 48 else b""))
+        with pytest.raises(ValueError):
+            W.load_tf_checkpoint(prefix)
+    open(prefix + ".index", "wb").write(idx)
+    assert len(W.load_tf_checkpoint(prefix)) == len(v)
+
+
 def _same(a, b):
     assert set(a) == set(b)
     for k in a:
