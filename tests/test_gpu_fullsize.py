@@ -69,7 +69,7 @@ def test_proposal_net_full_depth_davis_shape():
         assert abs(x["score"] - y["score"]) <= 0.011 and np.abs(np.array(x["bbox"]) - np.array(y["bbox"])).max() <= 0.11
     # and the whole CPU net agrees with the GPU net where floats are compared with a tolerance
     common = np.intersect1d(p.roi_idx[0, :n].cpu().numpy(), inter["proposal_idx"])
-    assert len(common) >= 95, len(common)                  # near-ties may swap a few of the 100 between the two nets
+    assert len(common) >= 98, len(common)                  # near-ties may swap one or two of the 100 between the two nets (measured: 100 shared, tests/test_gpu_error_budget.py)
 
 
 def test_proposal_net_full_depth_configs4_shape():

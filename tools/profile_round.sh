@@ -7,21 +7,22 @@ set -u
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
-export PREMVOS_TUNE_CACHE=$OUT/${TAG}_tune_choices.json
-rm -f "$PREMVOS_TUNE_CACHE"
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1      # fills the tune cache
+# (round 3: the conv configurations come from the shipped table premvos_amd/tune_gfx950.json -- tools/make_tune_table.py -- so
+#  there is no per-run tune cache to fill any more; the profiled runs use one pipeline step per bench step: --scaling weak)
+cp premvos_amd/tune_gfx950.json "$OUT/${TAG}_tune_choices.json"
+W="--scaling weak --file-to-file 0"
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 for mode in serial concurrent; do
   [ $mode = serial ] && export PREMVOS_PIPELINE_SERIAL=1 || unset PREMVOS_PIPELINE_SERIAL
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof_$mode" -o bench -- \
-    python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_prof_$mode.log" 2>&1
+    python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline $W > "$OUT/${TAG}_prof_$mode.log" 2>&1
   grep '^{' "$OUT/${TAG}_prof_$mode.log" | tail -1 > "$OUT/${TAG}_bench_under_rocprof_$mode.json"
 done
 export PREMVOS_PIPELINE_SERIAL=1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_$c" -o pmc -- \
-    python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/${TAG}_pmc_$c.log" 2>&1
+    python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline $W > "$OUT/${TAG}_pmc_$c.log" 2>&1
 done
 unset PREMVOS_PIPELINE_SERIAL
 cd "$REPO"
@@ -35,8 +36,8 @@ cp "$OUT/${TAG}_conv_hbm_traffic.json" profiles/${TAG}_conv_hbm_traffic.json    
    python "$REPO/tools/time_corr.py" 16 > "$OUT/${TAG}_time_corr.log" 2>&1)
 cp "$(find $OUT/${TAG}_prof_corr -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_corr_kernel_stats.csv"; rm -rf "$OUT/${TAG}_prof_corr"
 # 5. two ranks through the self-launching path (gloo: both ranks share this box's one GPU; RCCL needs a device per rank)
-PREMVOS_BENCH_BACKEND=gloo python bench.py --gpus 2 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline \
-   > "$OUT/${TAG}_bench_2ranks_gloo.log" 2>&1
+PREMVOS_BENCH_BACKEND=gloo python bench.py --gpus 2 --batch 4 --frames 30 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline \
+   --file-to-file 0 > "$OUT/${TAG}_bench_2ranks_gloo.log" 2>&1           # strong scaling: 30 frame pairs = 8 chunks of 4 (last ragged) over 2 ranks
 grep '^{' "$OUT/${TAG}_bench_2ranks_gloo.log" | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
 python tools/layer_table.py > "$OUT/${TAG}_layer_table.txt" 2>&1
 python bench.py > "$OUT/${TAG}_bench_fp32.log" 2>&1

@@ -6,7 +6,8 @@
 // progress instead of hanging.
 //
 //   hipcc -O2 -std=c++17 tools/stress_abi.cpp -Iinclude -Lpremvos_amd/csrc -lpremvos_hip -Wl,-rpath,$PWD/premvos_amd/csrc -o /tmp/stress_abi
-//   /tmp/stress_abi <threads> <launches per thread> <graph every> [<mode: 0 eager+graphs, 1 eager only, 2 global-mode capture>]
+//   /tmp/stress_abi <threads> <launches per thread> <graph every> [<mode: 0 eager + thread-local captures (the supported pattern),
+//        1 eager only, 2 global-mode captures (expected to disturb the other threads), 3 = mode 0 + synchronous hipMemcpy (the hazard)>]
 //
 // Exit code 0 = all launches done and verified, 2 = wrong result, 3 = a thread made no progress for 60 s, 4 = API error.
 #include <hip/hip_runtime.h>
@@ -42,7 +43,8 @@
     }                                                                                            \
   } while (0)
 
-static std::atomic<int> failed{0};
+static std::atomic<int> failed{0}, ready{0};
+static int nthreads = 0;
 static std::vector<std::atomic<long>*> progress;
 
 static float frand(unsigned& s) {
@@ -112,11 +114,32 @@ static void worker(int tid, long launches, int graph_every, int mode) {
   PVCHECK(sequence());
   HIPCHECK(hipStreamSynchronize(st));
   HIPCHECK(hipMemcpy(ref.data(), y3, ref.size() * 4, hipMemcpyDeviceToHost));
-  auto verify = [&]() -> bool {
-    if (hipStreamSynchronize(st) != hipSuccess) return false;
-    if (hipMemcpy(got.data(), y3, got.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    return memcmp(got.data(), ref.data(), got.size() * 4) == 0;
+  // Results come back through THIS thread's stream (hipMemcpyAsync + hipStreamSynchronize): calls that are legal on any thread
+  // while another thread captures.  mode 3 uses the synchronous hipMemcpy instead -- a legacy-default-stream operation, which
+  // the runtime refuses ("operation not permitted when stream is capturing") and which invalidates the OTHER thread's capture
+  // even in thread-local capture mode: the hazard behind the "no capture while other host threads use the GPU" rule of the
+  // drivers (every .cpu() of a torch tensor is such a call).  1 = ok, 0 = wrong bytes, -1 = API error.
+  float* pinned = nullptr;
+  HIPCHECK(hipHostMalloc(&pinned, got.size() * 4));
+  auto verify = [&]() -> int {
+    hipError_t e;
+    if (mode == 3) {
+      if ((e = hipStreamSynchronize(st)) != hipSuccess || (e = hipMemcpy(pinned, y3, got.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) {
+        fprintf(stderr, "thread %d: synchronous copy refused: %s\n", tid, hipGetErrorString(e));
+        return -1;
+      }
+    } else {
+      if ((e = hipMemcpyAsync(pinned, y3, got.size() * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+          (e = hipStreamSynchronize(st)) != hipSuccess) {
+        fprintf(stderr, "thread %d: async copy / sync failed: %s\n", tid, hipGetErrorString(e));
+        return -1;
+      }
+    }
+    return memcmp(pinned, ref.data(), got.size() * 4) == 0 ? 1 : 0;
   };
+  // every thread finishes its set-up (hipMalloc, synchronous copies: legacy-stream operations) before anyone captures
+  ready.fetch_add(1);
+  while (ready.load() < nthreads && !failed.load()) std::this_thread::yield();
   long done = 0, it = 0;
   while (done < launches && !failed.load()) {
     ++it;
@@ -136,16 +159,20 @@ static void worker(int tid, long launches, int graph_every, int mode) {
       PVCHECK(sequence());
       done += 4;
     }
-    if (it % 500 == 0 && !verify()) {
-      fprintf(stderr, "thread %d: wrong result after %ld launches\n", tid, done);
-      failed.store(2);
-      return;
+    if (it % 500 == 0) {
+      const int v = verify();
+      if (v != 1) {
+        if (v == 0) fprintf(stderr, "thread %d: WRONG RESULT after %ld launches\n", tid, done);
+        failed.store(v == 0 ? 2 : 4);
+        return;
+      }
     }
     progress[tid]->store(done);
   }
-  if (!failed.load() && !verify()) {
-    fprintf(stderr, "thread %d: wrong final result\n", tid);
-    failed.store(2);
+  if (!failed.load()) {
+    const int v = verify();
+    if (v == 0) fprintf(stderr, "thread %d: WRONG final result\n", tid);
+    if (v != 1) failed.store(v == 0 ? 2 : 4);
   }
   progress[tid]->store(launches + 1);
 }
@@ -155,6 +182,7 @@ int main(int argc, char** argv) {
   const long launches = argc > 2 ? atol(argv[2]) : 200000;
   const int graph_every = argc > 3 ? atoi(argv[3]) : 50;
   const int mode = argc > 4 ? atoi(argv[4]) : 0;
+  nthreads = threads;
   for (int i = 0; i < threads; ++i) progress.push_back(new std::atomic<long>(0));
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> th;
