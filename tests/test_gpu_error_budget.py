@@ -18,8 +18,12 @@ from oracle import proposal_oracle as PO  # noqa: E402
 from oracle import pwc_oracle as O  # noqa: E402
 from oracle import refinement_oracle as RO  # noqa: E402
 
-MODES = [("implicit_gemm_only", {"PREMVOS_FORCE_KERNEL": "igemm"}), ("shipped_table", {}),
-         ("f4x4_forced", {"PREMVOS_FORCE_KERNEL": "wino4"})]
+# (name, environment, MFMA arithmetic of the dense convs, held to the fp32 bars?)
+MODES = [("implicit_gemm_only", {"PREMVOS_FORCE_KERNEL": "igemm"}, "fp32", True), ("shipped_table", {}, "fp32", True),
+         ("f4x4_forced", {"PREMVOS_FORCE_KERNEL": "wino4"}, "fp32", True),
+         # the optional bf16-MFMA modes at FULL depth (configs[2] / [4] name bf16): split-bf16 (hi.hi + hi.lo +
+         # lo.hi, fp32 accumulate) must clear the same bars as fp32; plain bf16 is recorded, not asserted (it does not)
+         ("bf16x3", {}, "bf16x3", True), ("bf16", {}, "bf16", False)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -48,21 +52,22 @@ def test_flow_error_budget(monkeypatch):
     with torch.no_grad():
         ref = O.pwc_forward(sd, x)
     rows = {}
-    for mode, env in MODES:
+    for mode, env, prec, bars in MODES:
         for k in ("PREMVOS_FORCE_KERNEL",):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        net = pwc_dc_net(None).cuda().eval()
+        net = pwc_dc_net(None, precision=prec).cuda().eval()
         net.load_state_dict(sd)
         got = net(x.cuda()).cpu()
         err = float((got - ref).abs().max())
         rows[mode] = {"flow_max_abs_err_px": err, "flow_max_abs": float(ref.abs().max()),
                       "rel_to_bar": err / (1e-3 * max(1.0, float(ref.abs().max()))), "layers": _families(net.plan(1, 512, 896).descs)}
-        assert err < 1e-3 * max(1.0, float(ref.abs().max())), (mode, err)
+        assert not bars or err < 1e-3 * max(1.0, float(ref.abs().max())), (mode, err)
     _record("flow_512x896", rows)
     assert rows["f4x4_forced"]["layers"].get("wino4x4", 0) >= rows["shipped_table"]["layers"].get("wino4x4", 0) > 0
     assert rows["implicit_gemm_only"]["layers"].keys() <= {"igemm", "direct"}
+    assert rows["bf16"]["flow_max_abs_err_px"] > 10 * rows["bf16x3"]["flow_max_abs_err_px"]        # plain bf16 is a different accuracy class
 
 
 def test_proposal_error_budget(monkeypatch):
@@ -74,11 +79,11 @@ def test_proposal_error_budget(monkeypatch):
     nh, nw = PO.custom_resize_shape(480, 854)
     (fb, fp, fl, fi), inter = PO.model_forward(w, CR.resize_linear_u8(img, nw, nh), intermediates=True)
     rows = {}
-    for mode, env in MODES:
+    for mode, env, prec, bars in MODES:
         monkeypatch.delenv("PREMVOS_FORCE_KERNEL", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        net = ProposalNet(w)
+        net = ProposalNet(w, precision=prec)
         detect_one_image(img, OfflinePredictor(net))
         p = net.plan(1, nh, nw)
         n = int(p.roi_count.item())
@@ -93,8 +98,8 @@ def test_proposal_error_budget(monkeypatch):
         rows[mode] = {"featuremap_rel_err": e_fm, "rpn_logits_rel_err": e_rpn, "rois": n,
                       "rpn_indices_shared_with_cpu_net": common, "rpn_indices_same_position": same_order,
                       "layers": _families(p.descs)}
-        assert e_fm < 1e-3 and e_rpn < 2e-3, (mode, e_fm, e_rpn)
-        assert common >= 95, (mode, common)
+        assert not bars or (e_fm < 1e-3 and e_rpn < 2e-3), (mode, e_fm, e_rpn)
+        assert not bars or common >= 95, (mode, common)
     _record("proposal_749x1333", rows)
     assert rows["f4x4_forced"]["layers"].get("wino4x4", 0) >= rows["shipped_table"]["layers"].get("wino4x4", 0)
 
@@ -112,11 +117,11 @@ def test_refinement_error_budget(monkeypatch):
             lg = RO.deeplab_logits(w, x)
         refs.append((lg, crop) + RO.output_layer(lg, crop, H, W))
     rows = {}
-    for mode, env in MODES:
+    for mode, env, prec, bars in MODES:
         monkeypatch.delenv("PREMVOS_FORCE_KERNEL", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        net = RefinementNet(w, 16)
+        net = RefinementNet(w, 16, precision=prec)
         p = net.refine(torch.from_numpy(img).cuda(), torch.tensor(boxes).cuda(), max_boxes=4, with_posterior=True)
         e_lg = e_post = 0.0
         flips = 0
@@ -127,5 +132,5 @@ def test_refinement_error_budget(monkeypatch):
             flips += int((p.mask[i].cpu().numpy() != rm).sum())
         rows[mode] = {"mask_logit_rel_err": e_lg, "posterior_max_abs_err": e_post, "mask_pixels_flipped_of": f"{flips}/{3 * H * W}",
                       "layers": _families(net.plan(4, H, W, True).descs)}
-        assert e_lg < 1e-3 and e_post < 1e-3, (mode, e_lg, e_post)
+        assert not bars or (e_lg < 1e-3 and e_post < 1e-3), (mode, e_lg, e_post)
     _record("refinement_385x385", rows)

@@ -41,18 +41,24 @@ def main():
     t0 = time.time()
     H, W = 480, 854
 
+    def free():
+        import gc
+        gc.collect()                     # plans hold their buffers through closures (reference cycles)
+        torch.cuda.empty_cache()
+
     def note(what):
         torch.cuda.synchronize()
-        print(f"[{time.time() - t0:6.0f} s] {what}: {len(ops._TUNE_CACHE)} signatures", flush=True)
+        free()
+        print(f"[{time.time() - t0:6.0f} s] {what}: {len(ops._TUNE_CACHE)} signatures, "
+              f"{torch.cuda.memory_allocated() / 2**30:.1f} GiB held", flush=True)
 
     sd, pg, ps, rw = synth.pwc_state_dict(0), synth.proposal_weights(0), synth.proposal_weights(1), synth.refinement_weights(0)
     for (h, w) in ([(H, W)] + ([(1080, 1920)] if a.with_1080p else [])):
         pipe = FramePipeline(sd, pg, ps, rw, batch=16, boxes_per_frame=20)
         fa, fb = synth.video_frames(16, h, w, 0)
         pipe.step(fa.cuda(), fb.cuda(), synth.boxes(16, 20, h, w, 0).cuda())
-        note(f"bench pipeline {h}x{w}")
         del pipe
-        torch.cuda.empty_cache()
+        note(f"bench pipeline {h}x{w}")
     if not a.quick:
         fa, fb = synth.video_frames(8, H, W, 0)
         fa, fb = fa.cuda(), fb.cuda()
@@ -60,12 +66,13 @@ def main():
             st = FlowStage(sd, batch=b, use_graph=False)
             st.run(fa[:b], fb[:b])
             del st
+            free()
         note("flow stages")
         for b in (8, 1, 2, 4):
             st = ProposalStage(pg, batch=b, rgb_input=True, use_graph=False)
             st.run(fa[:b])
             del st
-        torch.cuda.empty_cache()
+            free()
         note("proposal stages")
         net = RefinementNet(rw, 16, use_graph=False)
         boxes = synth.boxes(4, 40, H, W, 3)
@@ -73,12 +80,12 @@ def main():
             per = [boxes[g, :slots // 4] for g in range(4)]
             net.refine_packed(fa[:4], per, slots, 4)
             net._plans.clear()
-            torch.cuda.empty_cache()
+            free()
         note("packed refinement groups")
         for p in (20, 22, 24, 26, 18, 16, 28, 32, 40):
             net.refine(fa[0], boxes[0, :p].cuda(), max_boxes=p)
             net._plans.clear()
-            torch.cuda.empty_cache()
+            free()
         note("single-frame refinement")
     ops.save_tune_cache(a.out)
     table = json.load(open(a.out))
