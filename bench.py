@@ -173,7 +173,10 @@ def file_to_file(n_frames: int, chunk: int):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def roofline(pipe, batch):
+PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+
+
+def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32"):
     """Dominant kernel = conv_igemm_f32_kernel (every dense conv of the three nets).  HIP events around every one
     of its launches of one step, on the stream they are launched on; achieved = algorithmic FLOPs / time."""
     reps = 5
@@ -224,6 +227,21 @@ def roofline(pipe, batch):
     cb.record()
     cb.synchronize()
     ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
+    if net_prec != "fp32":
+        # the optional bf16-MFMA modes (never the headline): priced against the dense bf16 peak.  bf16x3 issues three MFMAs per
+        # product (hi.hi + hi.lo + lo.hi), so its issue fraction is 3x its algorithmic fraction.
+        fl = {k: v[0] for k, v in per_stage.items()}
+        tm = {k: v[1] for k, v in per_stage.items()}
+        st = [k for k in per_stage if k != "flow" or flow_prec != "fp32"]
+        a16 = sum(fl[k] for k in st) / (sum(tm[k] for k in st) * 1e-3) / 1e12
+        mult = 3.0 if net_prec == "bf16x3" else 1.0
+        return {"bound": "mfma", "kernel": f"conv_igemm_bf16_kernel<NPASS={int(mult)}> (fp32 activations split into bf16 hi(/lo) while staged, "
+                                           f"v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the stages {st}; flow on the fp32 pipe: {flow_prec == 'fp32'}",
+                "achieved": round(a16, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a16 / PEAK_BF16_TFLOPS, 4),
+                "mfma_issue_frac": round(mult * a16 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()},
+                "conv_ms_per_step": round(ms, 3), "launches_per_step": nl,
+                "note": "supplementary mode; the metric's line is the fp32 run (dtype f32)"}
     return {"bound": "mfma", "kernel": "the dense-conv step of the three nets on the fp32 MFMA pipe: conv_igemm_f32_kernel (implicit GEMM; "
                                        "incl. its k-slab / tail-split launches + reduce) or, where the plan-time autotuner measured it faster, "
                                        "wino_gemm_kernel + wino_output_kernel or the slab-free wino_fused_kernel (Winograd F(2x2,3x3) for 3x3 "
@@ -433,7 +451,7 @@ def main():
         from premvos_amd import ops
         out["conv_configurations"] = ops.tune_info()     # which table / rule froze the kernels (reproducibility)
         if not a.no_roofline:
-            out["roofline"] = roofline(pipe, B)
+            out["roofline"] = roofline(pipe, B, net_prec, flow_prec)
         # secondary: the same path measured FILE TO FILE (JPEG decode, .flo / JSON / COCO-RLE writing included) by the streaming
         # driver -- by THIS run at N = 1, after the timed region; `value` above is the HBM-resident metric, never this
         if world == 1 and a.frame == "480p" and a.file_to_file > 0 and prec == "fp32":

@@ -32,9 +32,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 namespace {
 
-#ifndef PV_OCC
-#define PV_OCC 3
-#endif
 constexpr int BK = 16;           // k granularity of the packed weights (k_pad % 16 == 0)
 
 // SPLITK: blockIdx.z owns k-steps [z*kt_per, min(KT,(z+1)*kt_per)) and stores its raw partial tile to
@@ -46,7 +43,7 @@ constexpr int BK = 16;           // k granularity of the packed weights (k_pad %
 // the per-stage tap bookkeeping and 64-bit address arithmetic of the general path drop out (most ResNet / Xception
 // layers; the scalar+vector work between the barrier and the first MFMA of a stage was ~15 % of a stage).
 template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16, bool PW = false>
-__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) ? PV_OCC : 1) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
+__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) ? 3 : 1) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;

@@ -40,8 +40,10 @@ class Unsupported(ValueError):
     """A valid JPEG outside what the GPU decoder covers."""
 
 
-def enabled() -> bool:
-    return os.environ.get("PREMVOS_GPU_JPEG", "0") not in ("", "0")
+def enabled(default: str = "0") -> bool:
+    """PREMVOS_GPU_JPEG=1 / 0; unset: ``default`` (the stage drivers keep the library reader of the reference's scripts, the
+    streaming driver turns the GPU path on -- same bytes either way, tests/test_gpu_jpeg.py)."""
+    return os.environ.get("PREMVOS_GPU_JPEG", default) not in ("", "0")
 
 
 class _PinnedPool:
@@ -192,7 +194,7 @@ def stack_frames(items, device="cuda", bgr: bool = False) -> torch.Tensor:
     return torch.stack([to_device(i, device, bgr) for i in items])
 
 
-def loader():
+def loader(default: str = "0"):
     """The per-frame function of a driver's decode-ahead pool: file name -> host RGB array (default) or, with PREMVOS_GPU_JPEG=1,
     the entropy-decoded frame for ``stack_frames`` / ``to_device`` to finish on the GPU."""
-    return host_stage if enabled() else _pil_rgb
+    return host_stage if enabled(default) else _pil_rgb

@@ -39,6 +39,11 @@ cp "$(find $OUT/${TAG}_prof_corr -name '*kernel_stats.csv' | head -1)" "$OUT/${T
 PREMVOS_BENCH_BACKEND=gloo python bench.py --gpus 2 --batch 4 --frames 30 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline \
    --file-to-file 0 > "$OUT/${TAG}_bench_2ranks_gloo.log" 2>&1           # strong scaling: 30 frame pairs = 8 chunks of 4 (last ragged) over 2 ranks
 grep '^{' "$OUT/${TAG}_bench_2ranks_gloo.log" | tail -1 > "$OUT/${TAG}_bench_2ranks_gloo.json"
+# 6. the optional bf16-MFMA modes (configs[2] / [4] name bf16; never the headline): one line each, priced against the bf16 peak
+for prec in mixed-bf16x3 mixed-bf16; do
+  python bench.py --precision $prec --steps 5 --warmup 2 --no-cpu-baseline $W > "$OUT/${TAG}_bench_$prec.log" 2>&1
+  grep '^{' "$OUT/${TAG}_bench_$prec.log" | tail -1 > "$OUT/${TAG}_bench_$prec.json"
+done
 python tools/layer_table.py > "$OUT/${TAG}_layer_table.txt" 2>&1
 python bench.py > "$OUT/${TAG}_bench_fp32.log" 2>&1
 grep '^{' "$OUT/${TAG}_bench_fp32.log" | tail -1 > "$OUT/${TAG}_bench_fp32.json"
