@@ -126,22 +126,24 @@ class _FeedData:
     frame so the engine can refine ALL its boxes in one batched GPU pass the first time any of them is asked for."""
 
     def set_up_data_for_image(self, image, boxes):
-        obj_data = {}
-        frame_u8 = np.ascontiguousarray(np.asarray(image)[:, :, :3], dtype=np.uint8)
-        image = image / 255
-        label = np.zeros(image.shape[:2] + (1,), dtype=np.uint8)
-        for box_id, box in enumerate(boxes):
-            x0, y0, x1, y1 = box
-            x1 = x1 + x0
-            y1 = y1 + y0
-            obj_data[box_id] = {DataKeys.IMAGES: image, DataKeys.SEGMENTATION_LABELS: label, DataKeys.IMAGE_FILENAMES: "",
-                                DataKeys.BBOXES_y0x0y1x1: [y0, x0, y1, x1], DataKeys.OBJ_TAGS: str(box_id)}
-        if len(obj_data) > 0:
-            self._frames[id(obj_data)] = (obj_data, frame_u8)        # keeps obj_data alive while it is the current image
-            while len(self._frames) > 2:
-                self._frames.pop(next(iter(self._frames)))
-            return obj_data
-        return None
+        """The reference's example table for one frame (FewShotFeedSegmentationDataset.py:35-51): {box index: example} with the
+        frame scaled to [0, 1], an all-zero label plane, the box converted from x, y, w, h to y0, x0, y1, x1 and the index as
+        the object tag -- or None when the frame has no boxes."""
+        if len(boxes) == 0:
+            return None
+        pixels = np.asarray(image)
+        scaled, blank = pixels / 255, np.zeros(pixels.shape[:2] + (1,), dtype=np.uint8)
+
+        def example(k, xywh):
+            x, y, w, h = xywh
+            return {DataKeys.IMAGES: scaled, DataKeys.SEGMENTATION_LABELS: blank, DataKeys.IMAGE_FILENAMES: "",
+                    DataKeys.BBOXES_y0x0y1x1: [y, x, y + h, x + w], DataKeys.OBJ_TAGS: str(k)}
+        table = {k: example(k, b) for k, b in enumerate(boxes)}
+        # remember the uint8 frame of the (at most two) most recent tables: the first box asked for refines them all at once
+        self._frames[id(table)] = (table, np.ascontiguousarray(pixels[:, :, :3], dtype=np.uint8))
+        while len(self._frames) > 2:
+            self._frames.pop(next(iter(self._frames)))
+        return table
 
     def __init__(self):
         self._frames: "OrderedDict[int, tuple]" = OrderedDict()
