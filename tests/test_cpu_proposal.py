@@ -99,3 +99,44 @@ def test_small_oracle_forward_runs():
     (fb, fp, fl, fi), inter = P.model_forward(w, img, (1, 1, 1, 1), intermediates=True)
     assert inter["featuremap"].shape == (1, 1024, 4, 6)
     assert fb.shape[0] == fp.shape[0] <= 20 and inter["proposals"].shape[0] <= 100
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# property tests ("restate carefully, test tie cases with hypothesis")
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+def _iou_exact(a, b):
+    """IoU of two boxes with integer corners in exact rational arithmetic (as a float64 quotient of integers)."""
+    iw, ih = min(a[2], b[2]) - max(a[0], b[0]), min(a[3], b[3]) - max(a[1], b[1])
+    if iw <= 0 or ih <= 0:
+        return 0.0
+    inter = iw * ih
+    return inter / float((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+
+
+@settings(max_examples=60, deadline=None, derandomize=True)
+@given(st.integers(0, 2 ** 31), st.integers(2, 40), st.sampled_from([0.3, 0.5, 0.7]))
+def test_nms_and_topk_against_an_independent_greedy_formulation_with_ties(seed, n, thresh):
+    """tf.image.non_max_suppression as the reference calls it (model.py:205-212): candidates in descending score order, ties
+    to the lower index; a candidate is kept unless its IoU with an already kept box EXCEEDS the threshold.  Integer corners and
+    scores from a four-value set make every comparison exact, so an independently written greedy loop must agree index for index."""
+    rng = np.random.default_rng(seed)
+    x0, y0 = rng.integers(0, 30, n), rng.integers(0, 30, n)
+    boxes = np.stack([x0, y0, x0 + rng.integers(1, 25, n), y0 + rng.integers(1, 25, n)], 1).astype(np.float32)
+    if n > 4:
+        boxes[n // 2] = boxes[0]                                   # exact duplicates (IoU 1) and
+        boxes[n - 1] = boxes[1]
+    scores = rng.choice(np.array([0.9, 0.5, 0.5, 0.1], np.float32), n)      # many equal scores
+    order = sorted(range(n), key=lambda i: (-float(scores[i]), i))
+    assert list(P.topk_indices(scores, n)) == order
+    keep = []
+    for i in order:
+        if all(_iou_exact(boxes[i], boxes[j]) <= thresh for j in keep):
+            keep.append(i)
+    got = P.nms_tf(boxes[:, [1, 0, 3, 2]], scores, n, thresh)
+    # exact rational IoU vs the fp32 quotient of the TF kernel: identical decisions unless an IoU equals the threshold to 1e-6
+    close = any(abs(_iou_exact(boxes[i], boxes[j]) - thresh) < 1e-6 for i in range(n) for j in range(i))
+    assert close or list(got) == keep
+    k = max(1, n // 3)
+    assert list(P.nms_tf(boxes[:, [1, 0, 3, 2]], scores, k, thresh)) == keep[:k] or close

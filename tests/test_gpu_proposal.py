@@ -210,3 +210,37 @@ def test_mask_head_mode_mask():
     from premvos_amd.proposal.driver import fill_full_mask
     for box, m in zip(fb.astype(np.float64), ref_masks):
         assert np.array_equal(fill_full_mask(box, m, (160, 256)), P.fill_full_mask(box, m, (160, 256)))
+
+
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=20, deadline=None, derandomize=True)
+@given(st.integers(0, 2 ** 31), st.integers(2, 14), st.integers(2, 20))
+def test_rpn_proposals_kernel_fuzz_with_exact_ties_and_duplicate_boxes(seed, fh, fw):
+    """Property test of the fused top-k + decode + clip + NMS kernel against the oracle on inputs built to collide: logits from a
+    five-value set (ties everywhere, also across the top-k boundary) and box deltas from a three-value set (many anchors decode
+    to bit-identical boxes, i.e. IoU exactly 1 and IoUs that recur).  Indices, order, scores and count must agree exactly."""
+    _lib, ops = _ops()
+    from premvos_amd.proposal import cell_anchors
+    rng = np.random.default_rng(seed)
+    lab = torch.from_numpy(rng.choice(np.array([-2.0, 0.0, 0.5, 0.5, 3.0], np.float32), (fh, fw, 15)))
+    box = torch.from_numpy(rng.choice(np.array([-0.25, 0.0, 0.5], np.float32), (fh, fw, 15, 4)))
+    h, w = fh * 16 + int(rng.integers(0, 16)), fw * 16 + int(rng.integers(0, 16))
+    dec = P.decode_bbox_target(box.numpy(), P.all_anchors(fh, fw)).reshape(-1, 4)
+    pb, ps, pidx = P.generate_rpn_proposals(dec, lab.numpy().reshape(-1), h, w)
+    rpn = ops.NHWC.alloc(1, fh, fw, 75)
+    rpn.buf[0, :, :, :15] = lab.cuda()
+    rpn.buf[0, :, :, 15:75] = box.reshape(fh, fw, 60).cuda()
+    ca = torch.from_numpy(cell_anchors()).cuda()
+    ob = torch.zeros((1, 100, 4), device="cuda")
+    osc = torch.zeros((1, 100), device="cuda")
+    oi = torch.zeros((1, 100), dtype=torch.int32, device="cuda")
+    oc = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.load().premvos_rpn_proposals_f32(
+        rpn.ptr, rpn.ps, 1, fh, fw, 15, 0, 15, ca.data_ptr(), 16.0, float(h), float(w), 1000, 100, 0.7, 0.0,
+        float(P.BBOX_DECODE_CLIP), ob.data_ptr(), osc.data_ptr(), oi.data_ptr(), oc.data_ptr(), _lib.current_stream()))
+    n = int(oc.item())
+    assert n == len(pidx), (n, len(pidx))
+    assert np.array_equal(oi[0, :n].cpu().numpy(), pidx.astype(np.int32))
+    assert np.array_equal(osc[0, :n].cpu().numpy(), ps)
