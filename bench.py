@@ -58,7 +58,7 @@ def parse():
                          "second image of a rank's last pair, ragged last chunk); a step = one pass over the video.  weak: every rank "
                          "owns --batch frames per step (rounds 1-2)")
     ap.add_argument("--frames", type=int, default=int(os.environ.get("PREMVOS_BENCH_FRAMES", "0")),
-                    help="strong scaling: frame pairs of the video (default 16 chunks = 16 x --batch)")
+                    help="strong scaling: frame pairs of the video (default 8 chunks = 8 x --batch: one chunk per GPU of an 8-GPU node per pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--file-to-file", type=int, default=int(os.environ.get("PREMVOS_BENCH_F2F_FRAMES", "128")), metavar="FRAMES",
@@ -345,7 +345,7 @@ def main():
                          synth.refinement_weights(0), batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec,
                          flow_precision=flow_prec)
     strong = a.scaling == "strong"
-    T = (a.frames if a.frames > 0 else 16 * B) if strong else B * world
+    T = (a.frames if a.frames > 0 else 8 * B) if strong else B * world
     xchg = ResultExchange(B, H, W, P_BOXES, dev) if use_dist else None
     if strong:
         # the product's own sharding of ONE video (premvos_amd.stream.run): chunk-aligned frame ranges; frame pair t = (t, t+1)
