@@ -192,6 +192,28 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
 #endif
 
   const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+  // NARROW (round 3, the 128x128 / 2x2-wave tile only): a column tile with at most 96 real columns -- the sixth tile of the
+  // 728-wide Xception layers holds 88 -- is computed with the four waves side by side in M (32 rows x 3 column blocks each)
+  // instead of 2 x 2 (64 x 64 each): every wave then multiplies 3/4 (or 1/2, 1/4) of a full tile and the workgroup finishes
+  // that much earlier.  Merely skipping the empty blocks in the 2x2 layout did not shorten the tile (its left waves still
+  // multiply a full 64x64); the 4x1 layout for ALL tiles reads 5 instead of 4 LDS fragments per 16 MFMAs and was slower
+  // overall (round 2) -- here it runs only where it removes work.  Same products, same k order: bit-identical results.
+  // Measured (profiles/r03_igemm_ab.txt): +3 % on the 728-wide layers with 32-deep stages (two workgroups per CU: a tile's
+  // duration is what the CU waits for); nothing with 16-deep stages (three per CU: the loop is not bound by how long a tile
+  // occupies its slot -- occupancy 1 / 2 / 3 / 4 give 0.65 / 0.77 / 0.83 / 0.82 of the matrix peak on an ideal shape).
+  constexpr bool NARROW_OK = BM == 128 && BN == 128 && WM == 2 && WN == 2 && !PIXSHUF && !SPLITK;
+  bool narrow = false;
+  int nvn = 0;
+  if constexpr (NARROW_OK) {
+#ifndef PV_DBG_NONARROW
+    const int real = p.cout - n0;                                   // kernel-uniform per workgroup
+    const bool wide_ok = (p.cout & 3) == 0 && (p.out_ps & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15u) == 0 &&
+                         (p.res == nullptr || ((p.res_ps & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15u) == 0)) &&
+                         (p.bias == nullptr || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0);
+    narrow = wide_ok && real > 0 && real <= 96;
+    nvn = (real + 31) / 32;
+#endif
+  }
   // One straight-line copy of the K loop per number of live column blocks (no per-block condition inside it: conditional
   // accumulator updates cost the kernel 45 VGPRs and a wave per SIMD when they were tried); the last stage is peeled so that
   // only it carries the run-time bound on its 8-deep groups.
@@ -231,7 +253,50 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
     compute(&lds[buf][wm0 * RS + frag_off], &lds[buf][(BM + wn0) * RS + frag_off], ends_matrix ? h_last : KB / 8);
     __syncthreads();
   };
-  if (nvalid == NTL) k_loop(std::integral_constant<int, NTL>{});
+  [[maybe_unused]] auto k_loop_narrow = [&](auto nv_tag) {
+    constexpr int NV = decltype(nv_tag)::value;                     // live 32-column blocks: 1 ... 3
+    auto accn = [&](int j) -> f32x16& { return acc[j >> 1][j & 1]; };
+    auto compute = [&](const float* a, const float* b, const int hcnt) {
+#pragma unroll
+      for (int h = 0; h < KB / 8; ++h) {
+        if (h >= hcnt) break;
+        const float4 af = *reinterpret_cast<const float4*>(a + h * 8);
+        float4 bf[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) bf[j] = *reinterpret_cast<const float4*>(b + j * 32 * RS + h * 8);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          accn(j) = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[j].x, accn(j), 0, 0, 0);
+          accn(j) = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[j].y, accn(j), 0, 0, 0);
+          accn(j) = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[j].z, accn(j), 0, 0, 0);
+          accn(j) = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[j].w, accn(j), 0, 0, 0);
+        }
+      }
+    };
+    const bool ends_matrix = kt_end == KT_all;
+    const int arow = 32 * wave * RS + frag_off, brow = BM * RS + frag_off;
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+      const int buf = kt & 1;
+      gload(kt_begin + kt + 1);
+      compute(&lds[buf][arow], &lds[buf][brow], KB / 8);
+      lstore(buf ^ 1);
+      __syncthreads();
+    }
+    const int buf = (KT - 1) & 1;
+    compute(&lds[buf][arow], &lds[buf][brow], ends_matrix ? h_last : KB / 8);
+    __syncthreads();
+  };
+  bool done = false;
+  if constexpr (NARROW_OK) {
+    if (narrow) {                                                   // workgroup-uniform
+      if (nvn == 3) k_loop_narrow(std::integral_constant<int, 3>{});
+      else if (nvn == 2) k_loop_narrow(std::integral_constant<int, 2>{});
+      else k_loop_narrow(std::integral_constant<int, 1>{});
+      done = true;
+    }
+  }
+  if (done) {
+  } else if (nvalid == NTL) k_loop(std::integral_constant<int, NTL>{});
   else if (NTL > 2 && nvalid == 2) k_loop(std::integral_constant<int, (NTL > 2 ? 2 : 0)>{});
   else if (NTL > 1 && nvalid == 1) k_loop(std::integral_constant<int, (NTL > 1 ? 1 : 0)>{});
   else k_loop(std::integral_constant<int, 0>{});
@@ -267,7 +332,20 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
       float* stg = lds_dyn;
 #pragma unroll 1
       for (int wr = 0; wr < WM; ++wr) {
-        if (wave / WN == wr) {
+        if (NARROW_OK && narrow) {                                 // waves 2 wr, 2 wr + 1 hold rows [64 wr, 64 wr + 64), blocks 0 .. nvn-1
+          if ((wave >> 1) == wr) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              if (j < nvn) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int row = (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                  stg[row * EP + j * 32 + (lane & 31)] = acc[(j >> 1) % MT][(j & 1) % NTL][r];
+                }
+              }
+            }
+          }
+        } else if (wave / WN == wr) {
 #pragma unroll
           for (int ni = 0; ni < NTL; ++ni)
 #pragma unroll
@@ -450,7 +528,10 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
   const int M = d.n * d.ho * d.wo;
   dim3 grid(premvos::cdiv(M, BM), premvos::cdiv(d.cout, BN));
   dim3 block(64 * WM * WN);
-  constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float);
+#ifndef PV_DBG_LDS_PAD
+#define PV_DBG_LDS_PAD 0          // developer builds: extra dynamic LDS per workgroup = fewer workgroups per CU (occupancy experiments)
+#endif
+  constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float) + PV_DBG_LDS_PAD;
   static const bool attr_done = [] {            // once per instantiation, thread-safe (the file drivers launch from several threads)
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>, LDS_BYTES);

@@ -16,6 +16,8 @@ LAYERS = [  # n, cin, cout, h, w, k, stride, dil
     (2, 128, 128, 32, 40, 3, 1, 2),       # atrous context layer (slab-free Winograd only)
     (1, 64, 96, 64, 112, 3, 2, 1),        # stride 2
     (2, 565, 2, 32, 56, 3, 1, 1),         # flow head: direct small-N kernel
+    (2, 64, 168, 30, 30, 1, 1, 1),        # last column tile holds 40 real columns: the 128x128 tile's narrow (4x1 waves) path, 2 blocks
+    (1, 96, 148, 40, 40, 1, 1, 1),        # ... 20 real columns: 1 block
 ]
 
 
