@@ -306,7 +306,9 @@ def _candidates(d: ConvDesc):
     if wino_applicable(d) or wino_atrous_applicable(d):
         # tile_hint 3 = the same algebra without slabs: one kernel, a workgroup walks all 16 components of its block
         # (stage_k = block id, see conv_wino_f32.hip: tile rows x couts / waves / stage depth); it also takes atrous layers
-        if os.environ.get("PREMVOS_WINOGRAD_FUSED", "1") != "0":
+        # (the slab-free kernel addresses its operands with 32-bit element offsets: csrc/conv_wino_f32.hip refuses larger tensors)
+        small = d.n * d.h * d.w * d.in_ps < (1 << 30) and 16 * d.cout_pad * _r(d.cin_pad, 16) < (1 << 30)
+        if small and os.environ.get("PREMVOS_WINOGRAD_FUSED", "1") != "0":
             out.extend((3, v, -1, 0, 0) for v in (() if d.cout <= 32 else (3, 5) if d.cout <= 64 else (0, 2, 4, 6)))
     if wino_applicable(d) and bool(d.wgt_wino4) and os.environ.get("PREMVOS_WINOGRAD4", "1") != "0":
         # tile_hint 4 = Winograd F(4x4,3x3) (csrc/conv_wino4_f32.hip): 4x fewer multiplies, 2.25x the input + output through slabs
@@ -533,6 +535,9 @@ def autotune(descs, device="cuda", reps: int = 4):
                     same = [c for c in _candidates(d) if numerics_key(d, c) == key]
                     best = _time_cands(d, same, lib, stream, reps) if len(same) > 1 else None
                     best = best or rule
+                    d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = best
+                    if lib.premvos_conv2d_f32(C.byref(d), stream) != 0:      # a configuration the kernel refuses (a limit the rule
+                        best = (0, 0, 0, 0, 0)                                # does not know): the library's own closed-form choice
                     _TUNE_STATE["heuristic"] += 1
                 _TUNE_CACHE[sig] = best or (0, 0, 0, 0, 0)
                 d.workspace, d.workspace_bytes = None, 0
