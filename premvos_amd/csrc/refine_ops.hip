@@ -82,6 +82,18 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const uint8_t* __rest
   }
 }
 
+// PREMVOS_ACT_SPLIT_BF16 (bit 8 of `act`): the depthwise result of four channels is stored as {hi(4 x bf16), lo(4 x bf16)} with
+// x = hi + lo, hi = bf16(x) (round to nearest even), lo = bf16(x - hi) -- 16 bytes in place of the four floats -- for
+// premvos_pwconv_bf16x3_split_f32 (csrc/pwconv_bf16x3_split.hip), which then stages pure bf16.
+__device__ __forceinline__ float4 split_or_plain(const float4 r, const bool split) {
+  if (!split) return r;
+  using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+  const bf16x4 hi = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
+  const bf16x4 lo = {(__bf16)(r.x - (float)hi[0]), (__bf16)(r.y - (float)hi[1]), (__bf16)(r.z - (float)hi[2]), (__bf16)(r.w - (float)hi[3])};
+  const uint2 h = __builtin_bit_cast(uint2, hi), l = __builtin_bit_cast(uint2, lo);
+  return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
+}
+
 // ------------------------------------------------------------------------------------------
 // Depthwise 3x3 conv (+stride, +atrous) with folded BatchNorm: out = act(sum_taps w*relu?(in) + bias).
 // HBM-bound; one thread per (output pixel, 4 channels), weights [9][C] (BN scale folded in).
@@ -117,10 +129,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
       const float4 bv = *reinterpret_cast<const float4*>(bias + cg * 4);
       acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
     }
-    if (act == PREMVOS_ACT_RELU) {
+    if ((act & 0xff) == PREMVOS_ACT_RELU) {
       acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
-    *reinterpret_cast<float4*>(out + pix * out_ps + cg * 4) = acc;
+    *reinterpret_cast<float4*>(out + pix * out_ps + cg * 4) = split_or_plain(acc, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
   }
 }
 
@@ -190,10 +202,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restr
       const int ox = ox0 + o;
       if (ox >= wo) break;
       float4 r = acc[o];
-      if (act == PREMVOS_ACT_RELU) {
+      if ((act & 0xff) == PREMVOS_ACT_RELU) {
         r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
       }
-      *reinterpret_cast<float4*>(out + (((long)b * ho + oy) * wo + ox) * out_ps + cg * 4) = r;
+      *reinterpret_cast<float4*>(out + (((long)b * ho + oy) * wo + ox) * out_ps + cg * 4) = split_or_plain(r, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
     }
   }
 }
@@ -288,10 +300,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
           for (int q = 0; q < TW; ++q) {
             if (ox0 + q * dil >= wo) break;
             float4 r = acc[o][q];
-            if (act == PREMVOS_ACT_RELU) {
+            if ((act & 0xff) == PREMVOS_ACT_RELU) {
               r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
             }
-            *reinterpret_cast<float4*>(orow + (long)(ox0 + q * dil) * out_ps) = r;
+            *reinterpret_cast<float4*>(orow + (long)(ox0 + q * dil) * out_ps) = split_or_plain(r, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
           }
         }
       }
@@ -466,7 +478,8 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
   PV_REQUIRE(premvos::aligned16(in) && premvos::aligned16(out) && premvos::aligned16(wgt) &&
                  (bias == nullptr || premvos::aligned16(bias)),
              "dwconv3x3: pointers must be 16-byte aligned");
-  PV_REQUIRE(act == PREMVOS_ACT_NONE || act == PREMVOS_ACT_RELU, "dwconv3x3: bad activation");
+  PV_REQUIRE((act & ~PREMVOS_ACT_SPLIT_BF16) == PREMVOS_ACT_NONE || (act & ~PREMVOS_ACT_SPLIT_BF16) == PREMVOS_ACT_RELU,
+             "dwconv3x3: bad activation");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (stride == 1 && (wo + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3) &&
       (ho + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3)) {   // register-tiled fast path (stride 2: row kernel wins)

@@ -107,9 +107,12 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
                 pk.wgt_wino4 = pack_winograd4(w, cin_pad, cout_pad, device)
         return pk
     hi = full.to(torch.bfloat16)
-    lo = (full - hi.float()).to(torch.bfloat16) if prec == _lib.PREC_BF16X3 else None
-    return PackedConv(hi.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec,
-                      lo.to(device).contiguous() if lo is not None else None)
+    if prec != _lib.PREC_BF16X3:
+        return PackedConv(hi.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec, None)
+    # hi and lo matrices in ONE allocation, lo right behind hi: premvos_pwconv_bf16x3_split_f32 addresses both with 32-bit offsets
+    # from one base
+    both = torch.stack([hi, (full - hi.float()).to(torch.bfloat16)]).to(device).contiguous()
+    return PackedConv(both[0], b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec, both[1])
 
 
 WINO_MIN_CIN = 16
@@ -551,6 +554,18 @@ def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):
     d = conv_desc(x, pk, out, **kw)
     ws = assign_workspace([d], x.buf.device)          # noqa: F841  (kept alive until the launch is enqueued)
     _lib.check(_lib.load().premvos_conv2d_f32(C.byref(d), _lib.current_stream()), "conv2d")
+    return out
+
+
+def pwconv_bf16x3_split(x: NHWC, pk: PackedConv, out: NHWC, act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None):
+    """Pointwise conv of an input whose producer stored it split into bf16 hi / lo (premvos_dwconv3x3_f32 with ACT_SPLIT_BF16);
+    ``pk`` packed with precision="bf16x3" (bf16 hi / lo matrices)."""
+    assert pk.precision == _lib.PREC_BF16X3 and pk.wgt_lo is not None and (pk.kh, pk.kw) == (1, 1) and x.c == pk.cin
+    assert (x.n, x.h, x.w) == (out.n, out.h, out.w) and out.c == pk.cout
+    _lib.check(_lib.load().premvos_pwconv_bf16x3_split_f32(
+        x.ptr, x.ps, x.n * x.h * x.w, x.c, pk.wgt.data_ptr(), pk.wgt_lo.data_ptr(), pk.k_pad, pk.cout, pk.cout_pad,
+        pk.bias.data_ptr() if pk.bias is not None else None, res.ptr if res is not None else None,
+        res.ps if res is not None else 0, out.ptr, out.ps, act, slope, _lib.current_stream()), "pwconv_bf16x3_split")
     return out
 
 

@@ -103,22 +103,34 @@ class _Plan:
         def release(v: NHWC):
             pool.setdefault((v.n, v.h, v.w, v.c), []).append(v)
 
-        def conv(x, name, out, **kw):
+        # bf16x3 mode: the depthwise half of a separable conv stores its result already split into bf16 hi / lo (in place of the
+        # floats) and the pointwise half runs on the kernel that stages pure bf16 (csrc/pwconv_bf16x3_split.hip)
+        split_pw = net.precision == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0"
+        self.split_pw = split_pw
+
+        def conv(x, name, out, split_in=False, **kw):
             pk = PK[name]
             d = ops.conv_desc(x, pk, out, **kw)
             self.descs.append(d)
             key = f"conv:{name}"
-            steps.append((key, lambda d=d: ops.run_desc(d)))
+            if split_in:
+                assert (pk.kh, pk.kw) == (1, 1) and not kw.get("stride") and not kw.get("pad")
+                steps.append((key, lambda x=x, pk=pk, out=out, kw=kw: ops.pwconv_bf16x3_split(
+                    x, pk, out, act=kw.get("act", ACT_NONE), slope=kw.get("slope", 0.1), res=kw.get("res"))))
+            else:
+                steps.append((key, lambda d=d: ops.run_desc(d)))
             self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
 
         def dwconv(x: NHWC, name: str, out: NHWC, stride=1, rate=1, pre_relu=False, act=ACT_NONE):
             k = DW[name]
             assert x.c == k.c and out.c == k.c
 
+            flags = act | (_lib.ACT_SPLIT_BF16 if split_pw else 0)     # (every depthwise conv of this net feeds one pointwise conv)
+
             def f(x=x, out=out, k=k):
                 _lib.check(lib.premvos_dwconv3x3_f32(x.ptr, x.ps, x.n, x.h, x.w, x.c, k.wgt.data_ptr(),
                                                      k.bias.data_ptr(), k.c_pad, out.ptr, out.ps, out.h, out.w, stride,
-                                                     rate, rate, rate, int(pre_relu), act, _lib.current_stream()),
+                                                     rate, rate, rate, int(pre_relu), flags, _lib.current_stream()),
                            "dwconv3x3")
             steps.append((f"dw:{name}", f))
             self.dw_bytes[f"dw:{name}"] = 4.0 * k.c * (x.n * x.h * x.w + out.n * out.h * out.w)
@@ -175,7 +187,7 @@ class _Plan:
                     res = sc
                 elif i == 2 and skip == "sum":
                     res = inp
-                conv(t, f"{prefix}/separable_conv{i + 1}_pointwise", o, act=act, res=res)
+                conv(t, f"{prefix}/separable_conv{i + 1}_pointwise", o, split_in=split_pw, act=act, res=res)
                 release(t)
                 if cur is not inp:
                     if f"{prefix}/separable_conv{i}" == DECODER_SKIP:
@@ -204,7 +216,7 @@ class _Plan:
         for i, r in enumerate(ATROUS_RATES, 1):
             t = alloc(P, fh, fh, 2048)
             dwconv(feat, f"aspp{i}_depthwise", t, rate=r, act=ACT_RELU)
-            conv(t, f"aspp{i}_pointwise", cat.slice(256 * (i + 1), 256), act=ACT_RELU)
+            conv(t, f"aspp{i}_pointwise", cat.slice(256 * (i + 1), 256), split_in=split_pw, act=ACT_RELU)
             release(t)
         aspp = alloc(P, fh, fh, 256)
         conv(cat, "concat_projection", aspp, act=ACT_RELU)
@@ -222,7 +234,7 @@ class _Plan:
             t = alloc(P, dh, dh, d.c)
             dwconv(d, f"decoder/decoder_conv{j}_depthwise", t, act=ACT_RELU)
             o = alloc(P, dh, dh, 256)
-            conv(t, f"decoder/decoder_conv{j}_pointwise", o, act=ACT_RELU)
+            conv(t, f"decoder/decoder_conv{j}_pointwise", o, split_in=split_pw, act=ACT_RELU)
             d = o
         self.decoder_out = d
         self.logits = alloc(P, dh, dh, 2)

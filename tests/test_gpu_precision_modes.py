@@ -97,3 +97,58 @@ def test_proposal_and_refinement_bf16x3_stay_within_fp32_tolerances():
     e3 = np.abs(rp.posterior[0].cpu().numpy() - rpost).max()
     print(f"refinement bf16x3: logits rel err {e2:.2e}, posterior abs err {e3:.2e}")
     assert e2 < 1e-3 and e3 < 1e-3
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,act,res", [(2, 25, 25, 728, 728, "none", True), (1, 49, 49, 256, 728, "relu", False),
+                                                    (3, 13, 17, 128, 130, "leaky", True), (1, 9, 9, 2048, 256, "relu", False),
+                                                    (1, 31, 29, 304, 256, "relu", False)])
+def test_split_depthwise_and_pointwise_bf16x3(n, h, w, cin, cout, act, res):
+    """Round 3: premvos_dwconv3x3_f32 with PREMVOS_ACT_SPLIT_BF16 stores {hi, lo} bf16 groups in place of its floats, and
+    premvos_pwconv_bf16x3_split_f32 multiplies them (hi.hi + hi.lo + lo.hi) -- against the fp64 convolution of the fp32
+    depthwise result: fp32-class (3e-5 of the output scale), with ragged M / N tiles, residual, bias, activation."""
+    from premvos_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    dw = torch.randn((cin, 1, 3, 3), generator=g) * (2.0 / 9) ** 0.5
+    wt = torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    r = torch.randn((n, cout, h, w), generator=g) if res else None
+    lib = _lib.load()
+    xin = ops.NHWC.alloc(n, h, w, cin)
+    xin.buf[..., :cin] = x.permute(0, 2, 3, 1).cuda()
+    cpad = (cin + 3) // 4 * 4
+    dwk = torch.zeros((9, cpad), device="cuda")
+    dwk[:, :cin] = dw.view(cin, 9).t().cuda()
+    bias0 = torch.zeros((cpad,), device="cuda")
+    outs = []
+    for flags in (0, _lib.ACT_SPLIT_BF16):
+        t = ops.NHWC.alloc(n, h, w, cin)
+        _lib.check(lib.premvos_dwconv3x3_f32(xin.ptr, xin.ps, n, h, w, cin, dwk.data_ptr(), bias0.data_ptr(), cpad, t.ptr, t.ps, h, w,
+                                             1, 1, 1, 1, 0, flags, _lib.current_stream()), "dw")
+        outs.append(t)
+    plain, split = outs
+    torch.cuda.synchronize()
+    # decode the split form: every 16 bytes = four bf16 hi, four bf16 lo
+    raw = split.buf.view(torch.int16).view(n, h, w, -1, 8)
+    hi = raw[..., :4].contiguous().view(torch.bfloat16).float().reshape(n, h, w, -1)
+    lo = raw[..., 4:].contiguous().view(torch.bfloat16).float().reshape(n, h, w, -1)
+    ref_dw = plain.buf
+    assert torch.equal(hi, ref_dw.to(torch.bfloat16).float())                          # hi = round-to-nearest-even bf16
+    assert ((hi + lo) - ref_dw).abs().max().item() <= 2.0 ** -15 * ref_dw.abs().max().item()
+    pk = ops.pack_conv(wt, b, precision="bf16x3")
+    out = ops.NHWC.alloc(n, h, w, cout + 4)
+    out.buf.fill_(5.0)
+    rin = None
+    if res:
+        rin = ops.NHWC.alloc(n, h, w, cout)
+        rin.buf[..., :cout] = r.permute(0, 2, 3, 1).cuda()
+    a = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY}[act]
+    ops.pwconv_bf16x3_split(split, pk, out.slice(0, cout), act=a, slope=0.1, res=rin)
+    torch.cuda.synchronize()
+    ref = F.conv2d(plain.torch().cpu().double(), wt.double(), b.double())
+    if res:
+        ref = ref + r.double()
+    ref = {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.1)}[act](ref)
+    got = out.slice(0, cout).torch().cpu().double()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    assert torch.all(out.buf[..., cout:] == 5.0)                                       # the channel window is respected
