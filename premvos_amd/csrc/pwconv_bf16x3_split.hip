@@ -35,9 +35,10 @@ struct PwArgs {
   const float* bias;
   const float* res;
   float* out;
+  float* out_split;      // optional second copy of the output as {hi, lo} bf16 groups (the next pointwise conv's input)
   long m;
   unsigned hi_off, lo_off;
-  int in_ps, cin4, k_pad, cout, cout_pad, res_ps, out_ps, act;
+  int in_ps, cin4, k_pad, cout, cout_pad, res_ps, out_ps, out_split_ps, act;
   float slope;
 };
 
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(NT) void pwconv_bf16x3_split_kernel(const PwArgs p)
             v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
           }
           *reinterpret_cast<float4*>(p.out + m * p.out_ps + col) = v;
+          if (p.out_split != nullptr) *reinterpret_cast<float4*>(p.out_split + m * p.out_split_ps + col) = premvos::split_bf16_group(v);
         }
       }
     } else {
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(NT) void pwconv_bf16x3_split_kernel(const PwArgs p)
 
 extern "C" int premvos_pwconv_bf16x3_split_f32(const void* in_split, int32_t in_ps, int64_t m, int32_t cin, const void* wgt_hi,
                                                const void* wgt_lo, int32_t k_pad, int32_t cout, int32_t cout_pad, const float* bias,
-                                               const float* res, int32_t res_ps, float* out, int32_t out_ps, int32_t act,
-                                               float slope, void* stream) {
+                                               const float* res, int32_t res_ps, float* out, int32_t out_ps, void* out_split,
+                                               int32_t out_split_ps, int32_t act, float slope, void* stream) {
   PV_REQUIRE(in_split && wgt_hi && wgt_lo && out, "pwconv_bf16x3_split: null pointer");
   PV_REQUIRE(m > 0 && m < (1L << 31) && cin > 0 && cout > 0, "pwconv_bf16x3_split: bad dims");
   PV_REQUIRE(in_ps % 4 == 0 && in_ps >= (cin + 3) / 4 * 4, "pwconv_bf16x3_split: in_ps must be a multiple of 4 and >= roundup(cin, 4)");
@@ -260,6 +262,11 @@ extern "C" int premvos_pwconv_bf16x3_split_f32(const void* in_split, int32_t in_
              "pwconv_bf16x3_split: in / wgt must be 16-byte aligned");
   PV_REQUIRE(out_ps >= cout && (res == nullptr || res_ps >= cout), "pwconv_bf16x3_split: pixel strides < cout");
   PV_REQUIRE(act == PREMVOS_ACT_NONE || act == PREMVOS_ACT_RELU || act == PREMVOS_ACT_LEAKY, "pwconv_bf16x3_split: bad activation");
+  PV_REQUIRE(out_split == nullptr || (cout % 4 == 0 && out_ps % 4 == 0 && out_split_ps % 4 == 0 && out_split_ps >= cout &&
+                                      premvos::aligned16(out) && premvos::aligned16(out_split) &&
+                                      (res == nullptr || (res_ps % 4 == 0 && premvos::aligned16(res))) &&
+                                      (bias == nullptr || premvos::aligned16(bias))),
+             "pwconv_bf16x3_split: a split second output needs cout %% 4 == 0 and 16-byte aligned pixels (out, out_split, res, bias)");
   static const bool attr_done = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwconv_bf16x3_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS_BYTES);
@@ -268,9 +275,9 @@ extern "C" int premvos_pwconv_bf16x3_split_f32(const void* in_split, int32_t in_
   (void)attr_done;
   PwArgs a;
   a.in = static_cast<const char*>(in_split);
-  a.bias = bias; a.res = res; a.out = out; a.m = m;
+  a.bias = bias; a.res = res; a.out = out; a.out_split = static_cast<float*>(out_split); a.m = m;
   a.in_ps = in_ps; a.cin4 = (cin + 3) / 4; a.k_pad = k_pad; a.cout = cout; a.cout_pad = cout_pad;
-  a.res_ps = res_ps; a.out_ps = out_ps; a.act = act; a.slope = slope;
+  a.res_ps = res_ps; a.out_ps = out_ps; a.out_split_ps = out_split_ps; a.act = act; a.slope = slope;
   // 32-bit operand offsets: the activations, and the two weight matrices together, must each span less than 4 GB
   const char* hi = static_cast<const char*>(wgt_hi);
   const char* lo = static_cast<const char*>(wgt_lo);

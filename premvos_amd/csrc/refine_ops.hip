@@ -82,17 +82,8 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const uint8_t* __rest
   }
 }
 
-// PREMVOS_ACT_SPLIT_BF16 (bit 8 of `act`): the depthwise result of four channels is stored as {hi(4 x bf16), lo(4 x bf16)} with
-// x = hi + lo, hi = bf16(x) (round to nearest even), lo = bf16(x - hi) -- 16 bytes in place of the four floats -- for
-// premvos_pwconv_bf16x3_split_f32 (csrc/pwconv_bf16x3_split.hip), which then stages pure bf16.
-__device__ __forceinline__ float4 split_or_plain(const float4 r, const bool split) {
-  if (!split) return r;
-  using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
-  const bf16x4 hi = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
-  const bf16x4 lo = {(__bf16)(r.x - (float)hi[0]), (__bf16)(r.y - (float)hi[1]), (__bf16)(r.z - (float)hi[2]), (__bf16)(r.w - (float)hi[3])};
-  const uint2 h = __builtin_bit_cast(uint2, hi), l = __builtin_bit_cast(uint2, lo);
-  return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
-}
+// PREMVOS_ACT_SPLIT_BF16 (bit 8 of `act`): the depthwise result of four channels is stored split (common.h: split_bf16_group)
+__device__ __forceinline__ float4 split_or_plain(const float4 r, const bool split) { return split ? premvos::split_bf16_group(r) : r; }
 
 // ------------------------------------------------------------------------------------------
 // Depthwise 3x3 conv (+stride, +atrous) with folded BatchNorm: out = act(sum_taps w*relu?(in) + bias).

@@ -557,15 +557,17 @@ def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):
     return out
 
 
-def pwconv_bf16x3_split(x: NHWC, pk: PackedConv, out: NHWC, act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None):
-    """Pointwise conv of an input whose producer stored it split into bf16 hi / lo (premvos_dwconv3x3_f32 with ACT_SPLIT_BF16);
-    ``pk`` packed with precision="bf16x3" (bf16 hi / lo matrices)."""
+def pwconv_bf16x3_split(x: NHWC, pk: PackedConv, out: NHWC, act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None,
+                        out_split: Optional[NHWC] = None):
+    """Pointwise conv of an input whose producer stored it split into bf16 hi / lo (premvos_dwconv3x3_f32 / an F(4x4) conv with
+    ACT_SPLIT_BF16, or this op's own ``out_split``); ``pk`` packed with precision="bf16x3" (bf16 hi / lo matrices)."""
     assert pk.precision == _lib.PREC_BF16X3 and pk.wgt_lo is not None and (pk.kh, pk.kw) == (1, 1) and x.c == pk.cin
     assert (x.n, x.h, x.w) == (out.n, out.h, out.w) and out.c == pk.cout
     _lib.check(_lib.load().premvos_pwconv_bf16x3_split_f32(
         x.ptr, x.ps, x.n * x.h * x.w, x.c, pk.wgt.data_ptr(), pk.wgt_lo.data_ptr(), pk.k_pad, pk.cout, pk.cout_pad,
         pk.bias.data_ptr() if pk.bias is not None else None, res.ptr if res is not None else None,
-        res.ps if res is not None else 0, out.ptr, out.ps, act, slope, _lib.current_stream()), "pwconv_bf16x3_split")
+        res.ps if res is not None else 0, out.ptr, out.ps, out_split.ptr if out_split is not None else None,
+        out_split.ps if out_split is not None else 0, act, slope, _lib.current_stream()), "pwconv_bf16x3_split")
     return out
 
 

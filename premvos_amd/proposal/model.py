@@ -82,8 +82,20 @@ class _Plan:
             d = ops.conv_desc(x, pk, out, **kw)
             self.descs.append(d)
             key = "conv:" + (uid or name)
-            steps.append((key, lambda d=d: ops.run_desc(d)))
+            # split_in / out_split are decided after the tuner has fixed the kernel families (see `chains` below)
+            rec = {"d": d, "pk": pk, "out": out, "split_in": None, "out_split": None}
+
+            def run(rec=rec, kw=kw):
+                if rec["split_in"] is not None:
+                    ops.pwconv_bf16x3_split(rec["split_in"], rec["pk"], rec["out"], act=kw.get("act", ACT_NONE), res=kw.get("res"),
+                                            out_split=rec["out_split"])
+                else:
+                    ops.run_desc(rec["d"])
+            steps.append((key, run))
             self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
+            return rec
+
+        chains: List = []       # (conv3 of the block before or None, conv1, conv2, conv3) of every bottleneck, in launch order
 
         self.img = alloc(b, h, w, 3)
         # conv0: pad [2,3] + 7x7 s2 VALID + BN + ReLU; pool0: pad [0,1] + 3x3 s2 VALID  (basemodel.py:79-82)
@@ -98,33 +110,36 @@ class _Plan:
                                                0.0, _lib.current_stream()), "maxpool")
         steps.append(("maxpool", pool))
 
-        def group(x: NHWC, g: int, feat: int, count: int, stride: int, tag: str = "") -> NHWC:
+        def group(x: NHWC, g: int, feat: int, count: int, stride: int, tag: str = "", before=None) -> NHWC:
             for i in range(count):
                 p = f"group{g}/block{i}"
                 s = stride if i == 0 else 1
                 t1 = alloc(x.n, x.h, x.w, feat)
-                conv(x, p + "/conv1", t1, uid=tag + p + "/conv1", act=ACT_RELU)
+                r1 = conv(x, p + "/conv1", t1, uid=tag + p + "/conv1", act=ACT_RELU)
                 if s == 2:        # pad [0,1] + VALID stride 2  (basemodel.py:54-56)
                     ho, wo = ops.out_size(x.h, 3, 2, 0, 1), ops.out_size(x.w, 3, 2, 0, 1)
                     t2 = alloc(x.n, ho, wo, feat)
-                    conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", stride=(2, 2), pad=(0, 0), act=ACT_RELU)
+                    r2 = conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", stride=(2, 2), pad=(0, 0), act=ACT_RELU)
                 else:
                     t2 = alloc(x.n, x.h, x.w, feat)
-                    conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", pad=(1, 1), act=ACT_RELU)
+                    r2 = conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", pad=(1, 1), act=ACT_RELU)
                 if p + "/convshortcut" in P:   # 1x1 stride s on x[:, :, :-1, :-1] == reading pixel (s*oy, s*ox)
                     sc = alloc(x.n, t2.h, t2.w, feat * 4)
                     conv(x, p + "/convshortcut", sc, uid=tag + p + "/convshortcut", stride=(s, s))
                 else:
                     sc = x
                 y = alloc(x.n, t2.h, t2.w, feat * 4)
-                conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
+                r3 = conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
+                chains.append((before, r1, r2, r3))
+                before = r3
                 x = y
+            self._last3 = before
             return x
 
         nb = net.num_blocks
         x = group(x, 0, 64, nb[0], 1)
-        x = group(x, 1, 128, nb[1], 2)
-        fm = group(x, 2, 256, nb[2], 2)
+        x = group(x, 1, 128, nb[1], 2, before=self._last3)
+        fm = group(x, 2, 256, nb[2], 2, before=self._last3)
         self.featuremap = fm
         fh, fw = fm.h, fm.w
         # rpn_head (model.py:30-51): 3x3 + ReLU, then class(15) + box(60) as one 1x1 conv
@@ -196,6 +211,26 @@ class _Plan:
             conv(up, "maskrcnn/conv", self.final_masks, act=ACT_SIGMOID)
         self.steps, self.buffers = steps, keep
         self.ws_splitk = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)
+        # bf16x3 mode, after the kernel families are fixed: a 3x3 layer that runs as F(4x4,3x3) stores its output as {hi, lo}
+        # bf16 groups (in place of the floats; its only reader is conv3) and conv3 runs on the kernel that stages pure bf16
+        # (csrc/pwconv_bf16x3_split.hip: 2x the rate of splitting fp32 activations in every column tile); that conv3 writes its
+        # output twice -- fp32 for the residual add / shortcut / RPN / RoIAlign, and split for the next block's conv1
+        self.split_layers = 0
+        if net.split_1x1:
+            ys_pool: Dict[tuple, NHWC] = {}      # one split copy per shape: it lives from a conv3 to the next block's conv1
+            for before, r1, r2, r3 in chains:
+                if before is not None and before["split_in"] is not None and r1["pk"].precision == _lib.PREC_BF16X3:
+                    o = before["out"]
+                    shape = (o.n, o.h, o.w, o.c)
+                    if shape not in ys_pool:
+                        ys_pool[shape] = alloc(*shape)
+                    before["out_split"] = r1["split_in"] = ys_pool[shape]
+                    self.split_layers += 1
+                if r2["d"].tile_hint == 4 and r2["d"].precision == _lib.PREC_F32 and r3["pk"].precision == _lib.PREC_BF16X3 \
+                        and r2["out"].ps % 4 == 0:
+                    r2["d"].act |= _lib.ACT_SPLIT_BF16
+                    r3["split_in"] = r2["out"]
+                    self.split_layers += 1
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def run(self, steps=None):
@@ -232,10 +267,17 @@ class ProposalNet:
         self._plans: Dict[tuple, _Plan] = {}
         self.cell_anchors_dev = torch.from_numpy(cell_anchors()).to(device)
         w = weights
+        # bf16x3 (split-fp32) mode: the 3x3 layers stay on the fp32 kernels -- Winograd F(4x4,3x3) spends 4x fewer multiplies
+        # (2x the rate of three bf16 MFMAs per product on these shapes) -- and only the 1x1 layers (47 % of the backbone's
+        # multiplies) run as hi.hi + hi.lo + lo.hi.  PREMVOS_BF16X3_HYBRID=0: every layer on the bf16 pipe, as in round 1.
+        import os
+        hybrid = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_HYBRID", "1") != "0"
+        self.split_1x1 = hybrid and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" and os.environ.get("PREMVOS_BF16X3_SPLIT_PROP", "1") != "0"
         for name in [k[:-2] for k in w if k.endswith("/W") and (k[:-2] + "/bn") in w]:
             scale, bias = _fold_bn(w[name + "/bn"])
-            self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale, precision=prec)
-        self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device, precision=prec)
+            lp = "fp32" if hybrid and tuple(w[name + "/W"].shape[2:]) == (3, 3) else prec
+            self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale, precision=lp)
+        self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device, precision="fp32" if hybrid else prec)
         self.packed["rpn/heads"] = ops.pack_conv(torch.cat([w["rpn/class/W"], w["rpn/box/W"]], 0),
                                                  torch.cat([w["rpn/class/b"], w["rpn/box/b"]], 0), device, precision=prec)
         hw = torch.cat([w["fastrcnn/class/W"], w["fastrcnn/box/W"], w["secondclassification/class/W"]], 0)

@@ -97,10 +97,11 @@ def test_proposal_error_budget(monkeypatch):
         same_order = int(np.sum(idx[:min(n, len(inter["proposal_idx"]))] == inter["proposal_idx"][:n]))
         rows[mode] = {"featuremap_rel_err": e_fm, "rpn_logits_rel_err": e_rpn, "rois": n,
                       "rpn_indices_shared_with_cpu_net": common, "rpn_indices_same_position": same_order,
-                      "layers": _families(p.descs)}
+                      "layers": _families(p.descs), "pointwise_layers_on_the_split_bf16_kernel": p.split_layers}
         assert not bars or (e_fm < 1e-3 and e_rpn < 2e-3), (mode, e_fm, e_rpn)
         assert not bars or common >= 95, (mode, common)
     _record("proposal_749x1333", rows)
+    assert rows["bf16x3"]["pointwise_layers_on_the_split_bf16_kernel"] > 0 == rows["shipped_table"]["pointwise_layers_on_the_split_bf16_kernel"]
     assert rows["f4x4_forced"]["layers"].get("wino4x4", 0) >= rows["shipped_table"]["layers"].get("wino4x4", 0)
 
 

@@ -152,3 +152,86 @@ def test_split_depthwise_and_pointwise_bf16x3(n, h, w, cin, cout, act, res):
     got = out.slice(0, cout).torch().cpu().double()
     assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
     assert torch.all(out.buf[..., cout:] == 5.0)                                       # the channel window is respected
+
+
+def _decode_split(buf, c):
+    """{hi(4 x bf16), lo(4 x bf16)} groups -> (hi, lo) float tensors [..., c]."""
+    raw = buf.view(torch.int16).view(*buf.shape[:-1], -1, 8)
+    hi = raw[..., :4].contiguous().view(torch.bfloat16).float().reshape(*buf.shape[:-1], -1)[..., :c]
+    lo = raw[..., 4:].contiguous().view(torch.bfloat16).float().reshape(*buf.shape[:-1], -1)[..., :c]
+    return hi, lo
+
+
+@pytest.mark.parametrize("n,h,w,feat", [(2, 23, 30, 128), (1, 14, 14, 256)])
+def test_split_bottleneck_chain_bf16x3(n, h, w, feat):
+    """Round 3, proposal net in bf16x3 mode: the 3x3 conv2 of a bottleneck runs as fp32 Winograd F(4x4,3x3) and stores {hi, lo} groups
+    (PREMVOS_ACT_SPLIT_BF16 on premvos_conv2d_f32, tile_hint 4); conv3 (1x1 + residual + ReLU) multiplies them on
+    premvos_pwconv_bf16x3_split_f32 and writes its output twice, fp32 and split; the next conv1 reads the split copy.  Against the
+    plain fp32 launches of the same layers / the fp64 convolution."""
+    from premvos_amd import _lib, ops
+    g = torch.Generator().manual_seed(feat + h)
+    x = torch.randn((n, feat, h, w), generator=g)
+    w2 = torch.randn((feat, feat, 3, 3), generator=g) * (2.0 / (9 * feat)) ** 0.5
+    w3 = torch.randn((4 * feat, feat, 1, 1), generator=g) * (2.0 / feat) ** 0.5
+    w1 = torch.randn((feat, 4 * feat, 1, 1), generator=g) * (2.0 / (4 * feat)) ** 0.5
+    b2, b3, b1 = (torch.randn((c,), generator=g) * 0.1 for c in (feat, 4 * feat, feat))
+    sc = torch.randn((n, 4 * feat, h, w), generator=g)
+    xin = ops.NHWC.alloc(n, h, w, feat)
+    xin.buf[..., :feat] = x.permute(0, 2, 3, 1).cuda()
+    scin = ops.NHWC.alloc(n, h, w, 4 * feat)
+    scin.buf[..., :4 * feat] = sc.permute(0, 2, 3, 1).cuda()
+    pk2 = ops.pack_conv(w2, b2, precision="fp32")
+    assert pk2.wgt_wino4 is not None
+    outs = []
+    for flag in (0, _lib.ACT_SPLIT_BF16):
+        t2 = ops.NHWC.alloc(n, h, w, feat)
+        d = ops.conv_desc(xin, pk2, t2, pad=(1, 1), act=ops.ACT_RELU, tile_hint=4)
+        ws = torch.empty((ops.workspace_bytes(d) + 3) // 4, dtype=torch.float32, device="cuda")
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        d.act |= flag
+        ops.run_desc(d)
+        outs.append(t2)
+    torch.cuda.synchronize()
+    plain2, split2 = outs
+    hi, lo = _decode_split(split2.buf, feat)
+    assert torch.equal(hi, plain2.buf[..., :feat].to(torch.bfloat16).float())
+    assert ((hi + lo) - plain2.buf[..., :feat]).abs().max().item() <= 2.0 ** -15 * plain2.buf.abs().max().item()
+    # the split flag is refused on every other kernel family (nothing would read such an output correctly by accident)
+    d = ops.conv_desc(xin, pk2, ops.NHWC.alloc(n, h, w, feat), pad=(1, 1), act=ops.ACT_RELU | _lib.ACT_SPLIT_BF16, tile_hint=(128 << 16) | 128)
+    with pytest.raises(_lib.PremvosError, match="SPLIT_BF16"):
+        ops.run_desc(d)
+    # conv3: split in, fp32 + split out
+    pk3 = ops.pack_conv(w3, b3, precision="bf16x3")
+    y, ys = ops.NHWC.alloc(n, h, w, 4 * feat), ops.NHWC.alloc(n, h, w, 4 * feat)
+    ops.pwconv_bf16x3_split(split2, pk3, y, act=ops.ACT_RELU, res=scin, out_split=ys)
+    torch.cuda.synchronize()
+    ref3 = F.relu(F.conv2d(plain2.torch().cpu().double(), w3.double(), b3.double()) + sc.double())
+    got3 = y.torch().cpu().double()
+    assert (got3 - ref3).abs().max().item() < 3e-5 * max(1.0, ref3.abs().max().item())
+    hi, lo = _decode_split(ys.buf, 4 * feat)
+    assert torch.equal(hi, y.buf[..., :4 * feat].to(torch.bfloat16).float())
+    assert ((hi + lo) - y.buf[..., :4 * feat]).abs().max().item() <= 2.0 ** -15 * y.buf.abs().max().item()
+    # the next conv1 on the split copy
+    pk1 = ops.pack_conv(w1, b1, precision="bf16x3")
+    t1 = ops.NHWC.alloc(n, h, w, feat)
+    ops.pwconv_bf16x3_split(ys, pk1, t1, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    ref1 = F.relu(F.conv2d(y.torch().cpu().double(), w1.double(), b1.double()))
+    assert (t1.torch().cpu().double() - ref1).abs().max().item() < 3e-5 * max(1.0, ref1.abs().max().item())
+
+
+def test_proposal_bf16x3_plan_uses_the_split_chain(monkeypatch):
+    """The bf16x3 proposal plan: 3x3 layers on the fp32 kernels (F(4x4,3x3) where the table says so -- forced here, the maps of a
+    small image are below the table's threshold), conv3 / conv1 of those blocks on the split kernel; same feature map as the fp32
+    net on a reduced-depth net."""
+    from premvos_amd import synth
+    from premvos_amd.proposal.model import ProposalNet
+    monkeypatch.setenv("PREMVOS_FORCE_KERNEL", "wino4")
+    wts = synth.proposal_weights(0, num_blocks=(1, 2, 3, 2))
+    img = synth.clip_frames(0, 1, 256, 384).cuda()
+    nets = {p: ProposalNet(wts, num_blocks=(1, 2, 3, 2), precision=p, use_graph=False) for p in ("fp32", "bf16x3")}
+    plans = {p: nets[p].run_resized(img) for p in nets}
+    torch.cuda.synchronize()
+    assert plans["bf16x3"].split_layers >= 4 and plans["fp32"].split_layers == 0
+    fa, fb = plans["fp32"].featuremap.torch(), plans["bf16x3"].featuremap.torch()
+    assert (fa - fb).abs().max().item() < 1e-3 * fa.abs().max().item()
