@@ -272,7 +272,9 @@ class ProposalNet:
         # multiplies) run as hi.hi + hi.lo + lo.hi.  PREMVOS_BF16X3_HYBRID=0: every layer on the bf16 pipe, as in round 1.
         import os
         hybrid = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_HYBRID", "1") != "0"
-        self.split_1x1 = hybrid and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" and os.environ.get("PREMVOS_BF16X3_SPLIT_PROP", "1") != "0"
+        # PREMVOS_BF16X3_SPLIT=0: no {hi, lo} activation layout anywhere; PREMVOS_BF16X3_SPLIT_PROP=0: not in this net (A/B: tools/dev/hyb.sh)
+        self.split_1x1 = hybrid and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" \
+            and os.environ.get("PREMVOS_BF16X3_SPLIT_PROP", "1") != "0"
         for name in [k[:-2] for k in w if k.endswith("/W") and (k[:-2] + "/bn") in w]:
             scale, bias = _fold_bn(w[name + "/bn"])
             lp = "fp32" if hybrid and tuple(w[name + "/W"].shape[2:]) == (3, 3) else prec

@@ -62,3 +62,9 @@ if os.environ.get("LT_PRECISION"):
     for k, (t, w, n) in sorted(kinds.items()):
         print(f"  {k[0]:7s} {k[1]:13s} x{n:2d}  {t:7.3f} ms  {w / t:6.1f} TF/s-eq")
     print("  split layers:", pipe.prop_g.plan.split_layers if hasattr(pipe.prop_g, "plan") else "?")
+if os.environ.get("LT_PRECISION"):
+    print("refinement net, layers by time:")
+    rr = sorted([r for r in rows if r[1] == "refine"], key=lambda r: -r[3] * r[5])
+    print(f"  total {sum(r[3] * r[5] for r in rr):.2f} ms/step")
+    for l, st, name, ms, tf, mult in rr[:28]:
+        print(f"  {ms * mult:7.3f} ms  {tf:6.1f} TF/s-eq  {name}")
