@@ -349,3 +349,51 @@ def test_binary_side_car_holds_what_the_json_holds(tmp_path):
             assert ("ReID" in x) == ("ReID" in y)
             if "ReID" in x:
                 assert np.abs(np.array(x["ReID"]) - np.array(y["ReID"])).max() < 1e-5 * max(1.0, np.abs(x["ReID"]).max())
+
+
+def test_acceptance_command_runs_end_to_end_on_a_synthetic_tree(tmp_path):
+    """tools/accept_davis.py on a tree laid out like the released one -- weights/PReMVOS_weights/... as TF
+    tensor-bundle checkpoints + the PWC pickle, data/DAVIS/{JPEGImages,Annotations}/480p -- with synthetic weights and frames:
+    step 1 reads every checkpoint, step 2 runs the streaming driver in a fresh process, step 3 (MergeTrack, the reference's own
+    program) is stood in for by an output/final/ that equals the annotations, step 4 evaluates J / F against them."""
+    import importlib.util
+    import sys
+    from PIL import Image
+    from premvos_amd import weights as W
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("accept_davis", os.path.join(repo, "tools", "accept_davis.py"))
+    A = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(A)
+    root = tmp_path / "premvos"
+    root.mkdir()
+    _make_tree(root, t=4)
+    wp = root / "weights" / "PReMVOS_weights"
+    for sub in ("optical_flow_net", "proposal_net/general_weights", "proposal_net/specific_weights", "refinement_net/specific_weights"):
+        (wp / sub).mkdir(parents=True)
+    os.replace(root / "weights" / "pwc.pth.tar", wp / "optical_flow_net" / "pwc_net.pth.tar")
+    W.save_tf_checkpoint(str(wp / "proposal_net/general_weights/proposal_general_weights"), W.proposal_weights_to_tf(PO.synth_weights(0, BLOCKS)))
+    W.save_tf_checkpoint(str(wp / "proposal_net/specific_weights/proposal_specific_weights"), W.proposal_weights_to_tf(PO.synth_weights(1, BLOCKS)),
+                         num_shards=2)
+    W.save_tf_checkpoint(str(wp / "refinement_net/specific_weights/refinement_specific_weights"),
+                         W.refinement_weights_to_tf(RO.synth_weights(0, MIDDLE)))
+    pal = [0, 0, 0, 128, 0, 0] + [0] * (3 * 254)
+    for sub in ("data/DAVIS/Annotations/480p/bear", "output/final/bear"):
+        (root / sub).mkdir(parents=True)
+        for t in range(4):
+            g = np.zeros((120, 200), np.uint8)
+            g[30 + 2 * t:80 + 2 * t, 50 + 3 * t:120 + 3 * t] = 1
+            im = Image.frombytes("P", (200, 120), g.tobytes())
+            im.putpalette(pal)
+            im.save(root / sub / f"{t:05d}.png")
+    cwd = os.getcwd()
+    try:
+        rc = A.main(["--root", str(root), "--skip-reid", "--tolerance", "100"])
+    finally:
+        os.chdir(cwd)
+    assert rc == 0
+    inter = root / "output" / "intermediate"
+    assert len(list((inter / "flow" / "bear").glob("*.flo"))) == 3
+    assert len(list((inter / "refined_proposals" / "bear").glob("*.json"))) == 4
+    r = json.loads((root / "output" / "premvos_amd_davis_eval.json").read_text())
+    assert r["mean_J"] == 1.0 and r["mean_F"] == 1.0 and r["sequences"] == 1
+    assert json.loads((root / "output" / "premvos_amd_manifest.json").read_text())["frames"] == 4
