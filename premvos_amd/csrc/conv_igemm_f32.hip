@@ -328,6 +328,19 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
                       (p.bias == nullptr || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0);
     constexpr int EP = BN + 4;                                   // row pitch of the staged block (floats)
     static_assert(WTM * EP <= 2 * BUF, "the staged wave row must fit the operand buffers");
+#ifdef PV_DBG_NOEPI             // developer phase ablation (tools/dev/ab_build.sh): no epilogue at all; the accumulators stay live
+    if (wide) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc += acc[mi][ni][r];
+      if (sacc == 12345.678f) p.out[tid] = sacc;
+      return;
+    }
+#endif
     if (wide) {                                                  // kernel-uniform
       float* stg = lds_dyn;
 #pragma unroll 1
@@ -380,6 +393,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
             } else if (p.act == PREMVOS_ACT_SIGMOID) {
               v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
             }
+#ifdef PV_DBG_NOSTORE           // developer phase ablation: everything but the global store
+            if (v.x == 12345.678f)
+#endif
             *reinterpret_cast<float4*>(p.out + (long)m * p.out_ps + col) = v;
           }
         }
