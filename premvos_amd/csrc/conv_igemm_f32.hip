@@ -242,6 +242,12 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
       }
     };
     const bool ends_matrix = kt_end == KT_all;       // this workgroup's last stage is the matrix's last stage
+#ifdef PV_DBG_NOFRAGPF           // developer A/B builds: the loop of rounds 1-3a (fragments read right before their MFMAs)
+    constexpr bool FRAG_PF = false;
+#else
+    constexpr bool FRAG_PF = KB == 16;      // (32-deep stages hold twice the staging registers: the second fragment set spilled)
+#endif
+    if constexpr (!FRAG_PF) {
     for (int kt = 0; kt + 1 < KT; ++kt) {
       const int buf = kt & 1;
       gload(kt_begin + kt + 1);
@@ -252,6 +258,58 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
     const int buf = (KT - 1) & 1;
     compute(&lds[buf][wm0 * RS + frag_off], &lds[buf][(BM + wn0) * RS + frag_off], ends_matrix ? h_last : KB / 8);
     __syncthreads();
+    } else {
+    // Fragment double buffering: the LDS reads of the NEXT 8-deep group are in flight while the MFMAs of the current one
+    // issue (two register sets), and the first group of the next stage is requested right behind the barrier, under the last
+    // row block's MFMAs of this stage -- before, every group began with ds_read + s_waitcnt lgkmcnt(0) (four exposed LDS
+    // round trips per stage and wave).  Same products in the same order: bit-identical results.
+    constexpr int H = KB / 8, NVV = NV > 0 ? NV : 1;
+    float4 af[2][MT], bf[2][NVV];
+    auto ldfrag = [&](const int set, const int buf, const int h) {
+      const float* a = &lds[buf][wm0 * RS + frag_off] + h * 8;
+      const float* b = &lds[buf][(BM + wn0) * RS + frag_off] + h * 8;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) af[set][mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS);
+#pragma unroll
+      for (int ni = 0; ni < NV; ++ni) bf[set][ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS);
+    };
+    auto mfma_rows = [&](const int set, const int mi0, const int mi1) {
+#pragma unroll
+      for (int mi = mi0; mi < mi1; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NV; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].x, bf[set][ni].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].y, bf[set][ni].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].z, bf[set][ni].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].w, bf[set][ni].w, acc[mi][ni], 0, 0, 0);
+        }
+    };
+    static_assert(H % 2 == 0, "the two fragment sets alternate per 8-deep group");
+    ldfrag(0, 0, 0);
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+      const int buf = kt & 1;
+      gload(kt_begin + kt + 1);
+#pragma unroll
+      for (int h = 0; h + 1 < H; ++h) {
+        ldfrag((h + 1) & 1, buf, h + 1);
+        mfma_rows(h & 1, 0, MT);
+      }
+      mfma_rows((H - 1) & 1, 0, MT - 1);
+      lstore(buf ^ 1);
+      __syncthreads();
+      ldfrag(0, buf ^ 1, 0);
+      mfma_rows((H - 1) & 1, MT - 1, MT);
+    }
+    const int buf = (KT - 1) & 1;
+    const int hcnt = ends_matrix ? h_last : H;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      if (h >= hcnt) break;
+      if (h + 1 < hcnt) ldfrag((h + 1) & 1, buf, h + 1);
+      mfma_rows(h & 1, 0, MT);
+    }
+    __syncthreads();
+    }
   };
   [[maybe_unused]] auto k_loop_narrow = [&](auto nv_tag) {
     constexpr int NV = decltype(nv_tag)::value;                     // live 32-column blocks: 1 ... 3
