@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
     ldfrag(0, 0, 0);
     for (int kt = 0; kt + 1 < KT; ++kt) {
       const int buf = kt & 1;
-      gload(kt_begin + kt + 1);
+      gload(kt_begin + kt + 1);       // (requesting a stage earlier -- right behind the previous barrier -- measured 1.3 % SLOWER)
 #pragma unroll
       for (int h = 0; h + 1 < H; ++h) {
         ldfrag((h + 1) & 1, buf, h + 1);
