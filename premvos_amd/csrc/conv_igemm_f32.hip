@@ -120,6 +120,15 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
   }
 
   float4 ra[A_PER_T], rb[B_PER_T];
+  // Interior stages of interior tiles of a 1x1 layer (all BM rows < M, all BN weight rows < cout_pad, and every stage but the
+  // matrix's last lies below cin_pad = k_pad rounded down): nothing to predicate -- plain requests, no zero fill, no branches.
+  [[maybe_unused]] auto gload_plain = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) ra[i] = *reinterpret_cast<const float4*>(rowbase[i] + c);
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + kt * KB);
+    c += KB;
+  };
   auto gload = [&](int kt) {
     if constexpr (PW) {
       const bool kok = c < p.cin_pad;
@@ -286,9 +295,18 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
     };
     static_assert(H % 2 == 0, "the two fragment sets alternate per 8-deep group");
     ldfrag(0, 0, 0);
-    for (int kt = 0; kt + 1 < KT; ++kt) {
+    auto stage = [&](const int kt, auto plain_tag) {
       const int buf = kt & 1;
-      gload(kt_begin + kt + 1);       // (requesting a stage earlier -- right behind the previous barrier -- measured 1.3 % SLOWER)
+      // (requesting a stage earlier -- right behind the previous barrier -- measured 1.3 % SLOWER)
+      if constexpr (decltype(plain_tag)::value) {
+        gload_plain(kt_begin + kt + 1);
+#ifndef PV_DBG_NOPIN_GLOAD
+        // a scheduling fence behind the requests: left alone, the scheduler reuses the fragment registers for all four of them and
+        // sinks them to right before their ds_write; with the fence two get registers of their own and the next group's fragment
+        // reads follow them (+1.7 % in the same-box A/B; other placements of the requests / fences measured equal or slower)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      } else gload(kt_begin + kt + 1);
 #pragma unroll
       for (int h = 0; h + 1 < H; ++h) {
         ldfrag((h + 1) & 1, buf, h + 1);
@@ -299,7 +317,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
       __syncthreads();
       ldfrag(0, buf ^ 1, 0);
       mfma_rows((H - 1) & 1, MT - 1, MT);
+    };
+    int kt = 0;
+#ifndef PV_DBG_NOPLAIN
+    if constexpr (PW && A_UNITS % NT == 0 && B_UNITS % NT == 0) {
+      // workgroup-uniform; stages kt + 1 <= KT_all - 2 hold only k < cin_pad (k_pad - cin_pad < KB)
+      const bool interior = m0 + BM <= M && n0 + BN <= p.cout_pad && (KT_all - 1) * KB <= p.cin_pad;
+      if (interior)
+        for (; kt_begin + kt + 1 < KT_all - 1 && kt + 1 < KT; ++kt) stage(kt, std::true_type{});
     }
+#endif
+    for (; kt + 1 < KT; ++kt) stage(kt, std::false_type{});
     const int buf = (KT - 1) & 1;
     const int hcnt = ends_matrix ? h_last : H;
 #pragma unroll
