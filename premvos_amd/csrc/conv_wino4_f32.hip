@@ -149,6 +149,12 @@ __global__ __launch_bounds__(256) void wino4_gemm_kernel(const float* __restrict
   lstore(0);
   __syncthreads();
   const int frag_off = (lane & 31) * RS + 4 * (lane >> 5);
+#ifdef PV_DBG_W4_OLDLOOP         // developer A/B builds: the loop as it was everywhere (fragments read right before their MFMAs)
+  constexpr bool FRAG_PF = false;
+#else
+  constexpr bool FRAG_PF = KB == 16;   // measured: +3 ... +8 % with 16-deep stages, -5 % with 32-deep ones (which keep the old loop)
+#endif
+  if constexpr (!FRAG_PF) {
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < KT) gload(kt + 1);
@@ -173,6 +179,58 @@ __global__ __launch_bounds__(256) void wino4_gemm_kernel(const float* __restrict
     }
     if (kt + 1 < KT) lstore(buf ^ 1);
     __syncthreads();
+  }
+  } else {
+  // The loop of conv_igemm_f32.hip (round 3): two fragment sets (the next 8-deep group's LDS reads in flight under the current
+  // group's MFMAs; the first group of the next stage requested right behind the barrier) and a scheduling fence behind the global
+  // requests.  Same products in the same order.
+  constexpr int H = KB / 8;
+  static_assert(H % 2 == 0, "the two fragment sets alternate per 8-deep group");
+  float4 af[2][MT], bf[2][NTL];
+  auto ldfrag = [&](const int set, const int buf, const int h) {
+    const float* a = &lds[buf][wm0 * RS + frag_off] + h * 8;
+    const float* b = &lds[buf][(BM + wn0) * RS + frag_off] + h * 8;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) af[set][mi] = *reinterpret_cast<const float4*>(a + mi * 32 * RS);
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni) bf[set][ni] = *reinterpret_cast<const float4*>(b + ni * 32 * RS);
+  };
+  auto mfma_rows = [&](const int set, const int mi0, const int mi1) {
+#pragma unroll
+    for (int mi = mi0; mi < mi1; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].x, bf[set][ni].x, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].y, bf[set][ni].y, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].z, bf[set][ni].z, acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].w, bf[set][ni].w, acc[mi][ni], 0, 0, 0);
+      }
+  };
+  ldfrag(0, 0, 0);
+  for (int kt = 0; kt + 1 < KT; ++kt) {
+    const int buf = kt & 1;
+    gload(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h + 1 < H; ++h) {
+      ldfrag((h + 1) & 1, buf, h + 1);
+      mfma_rows(h & 1, 0, MT);
+    }
+    mfma_rows((H - 1) & 1, 0, MT - 1);
+    lstore(buf ^ 1);
+    __syncthreads();
+    ldfrag(0, buf ^ 1, 0);
+    mfma_rows((H - 1) & 1, MT - 1, MT);
+  }
+  {
+    const int buf = (KT - 1) & 1;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      if (h + 1 < H) ldfrag((h + 1) & 1, buf, h + 1);
+      mfma_rows(h & 1, 0, MT);
+    }
+    __syncthreads();
+  }
   }
 
   // raw tile -> Ms[comp][tile][ncols], staged through the (now idle) operand LDS so that every lane stores 16 bytes
