@@ -9,7 +9,10 @@ again (premvos_amd.ops.autotune).  Shapes covered (480x854 frames, full-depth ne
   the stage drivers             1 frame per launch list (flow, proposals), refinement of 1 frame (18 ... 26 boxes) and packed groups
   bench.py --frame 1080p        (with --with-1080p)
 
-    python tools/make_tune_table.py [--out premvos_amd/tune_gfx950.json] [--with-1080p] [--quick]
+    python tools/make_tune_table.py [--out premvos_amd/tune_gfx950.json] [--with-1080p] [--quick] [--polish]
+
+A full exploration times each candidate 2 x 4 times: its ~1 % noise decides between near-equal configurations, so re-running it
+after a kernel change can LOSE (round 3: -2 % on the pipeline in a same-box A/B).  --polish is the safe refresh.
 """
 import argparse
 import json
@@ -19,8 +22,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PREMVOS_AUTOTUNE"] = "full"
-os.environ["PREMVOS_TUNE_TABLE"] = "0"
+POLISH = "--polish" in sys.argv       # keep every entry's arithmetic, re-time only its order-neutral knobs (ops._polish)
+os.environ["PREMVOS_AUTOTUNE"] = "polish" if POLISH else "full"
+if not POLISH:
+    os.environ["PREMVOS_TUNE_TABLE"] = "0"
 os.environ.pop("PREMVOS_TUNE_CACHE", None)
 
 import torch  # noqa: E402
@@ -33,6 +38,8 @@ def main():
     ap.add_argument("--out", default=ops.TUNE_TABLE)
     ap.add_argument("--with-1080p", action="store_true")
     ap.add_argument("--quick", action="store_true", help="bench shapes only")
+    ap.add_argument("--polish", action="store_true", help="start from the shipped table; re-time only order-neutral knobs (12 x 3 "
+                    "repetitions), replace an entry when another block / stage depth is >= 1.5 %% faster; results do not change")
     a = ap.parse_args()
     from premvos_amd.flow.driver import FlowStage
     from premvos_amd.pipeline import FramePipeline
