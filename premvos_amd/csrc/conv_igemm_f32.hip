@@ -307,12 +307,18 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
         __builtin_amdgcn_sched_barrier(0);
 #endif
       } else gload(kt_begin + kt + 1);
+#ifndef PV_DBG_NOSETPRIO
+      __builtin_amdgcn_s_setprio(1);       // a wave inside its MFMA run wins the issue arbitration over waves staging / waiting (+0.5 %)
+#endif
 #pragma unroll
       for (int h = 0; h + 1 < H; ++h) {
         ldfrag((h + 1) & 1, buf, h + 1);
         mfma_rows(h & 1, 0, MT);
       }
       mfma_rows((H - 1) & 1, 0, MT - 1);
+#ifndef PV_DBG_NOSETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       lstore(buf ^ 1);
       __syncthreads();
       ldfrag(0, buf ^ 1, 0);
