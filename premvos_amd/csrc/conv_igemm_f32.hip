@@ -488,8 +488,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
 #ifdef PV_DBG_NOSTORE           // developer phase ablation: everything but the global store
             if (v.x == 12345.678f)
 #endif
-*reinterpret_cast<float4*>(p.out + (long)m * p.out_ps + col) = v;      // (non-temporal stores: +1.5 % on HBM-bound layers
-                                                                                   //  alone, nothing in the pipeline -- not used)
+            // (non-temporal stores: +1.5 % on HBM-bound layers alone, nothing in the pipeline -- not used)
+            *reinterpret_cast<float4*>(p.out + (long)m * p.out_ps + col) = v;
           }
         }
         if (wr + 1 < WM) __syncthreads();
