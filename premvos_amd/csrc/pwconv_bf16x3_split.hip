@@ -166,6 +166,7 @@ __global__ __launch_bounds__(NT) void pwconv_bf16x3_split_kernel(const PwArgs p)
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
     }
   };
+#ifdef PV_DBG_SPLIT_OLDLOOP      // developer A/B builds: the first loop of this kernel (fragments read right before their MFMAs)
   // stage kt is multiplied out of LDS buffer kt & 1; register set kt & 1 (stored one stage ago) takes stage kt + 2, set
   // (kt + 1) & 1 -- requested one stage ago -- goes to LDS for stage kt + 1
   auto step = [&](auto par_tag, const int kt) {
@@ -181,6 +182,73 @@ __global__ __launch_bounds__(NT) void pwconv_bf16x3_split_kernel(const PwArgs p)
     step(std::integral_constant<int, 1>{}, kt + 1);
   }
   if (kt < KT) step(std::integral_constant<int, 0>{}, kt);
+
+#else
+  // Late round 3 (the fp32 kernel's lesson, conv_igemm_f32.hip): TWO FRAGMENT sets -- the LDS reads of the next 16-deep group are
+  // in flight while the 12 MFMAs of the current one issue, and the first group of the next stage is requested right behind the
+  // barrier, under the last hi.hi MFMAs of this stage -- plus a scheduling fence behind the global requests and a raised issue
+  // priority over the MFMA run.  A group is only 12 x 32 cycles: before, its eight ds_read_b128 were waited for in full, twice
+  // per stage, with two waves per SIMD to cover them.  Same products in the same order.
+  static_assert(KS == 32, "two 16-deep groups per stage");
+  bf16x8 fah[2][2], fal[2][2], fbh[2][2], fbl[2][2];                   // [set][block]
+  auto ldfrag = [&](const int set, const int buf, const int sgrp) {
+    const char* a = lds + buf * BUF + wm0 * RSB + frag_off + sgrp * 32;
+    const char* b = lds + buf * BUF + 2 * PLANE + wn0 * RSB + frag_off + sgrp * 32;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      fah[set][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + mi * 32 * RSB));
+      fal[set][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + PLANE + mi * 32 * RSB));
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      fbh[set][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + ni * 32 * RSB));
+      fbl[set][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + PLANE + ni * 32 * RSB));
+    }
+  };
+  auto mfma_small = [&](const int set) {                                // lo.hi then hi.lo (small terms first)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[set][mi], fbh[set][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[set][mi], fbl[set][ni], acc[mi][ni], 0, 0, 0);
+  };
+  auto mfma_big = [&](const int set) {                                  // hi.hi
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[set][mi], fbh[set][ni], acc[mi][ni], 0, 0, 0);
+  };
+  // one register set of global requests here (ra0[0] ...): stage kt + 1 is requested at the top of stage kt
+  ldfrag(0, 0, 0);
+  for (int kt = 0; kt + 1 < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt > 0 || KT <= 1) gload(kt + 1, ra0[0], ra1[0], rb[0]);      // (stage 1 was requested before the loop)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    ldfrag(1, buf, 1);
+    mfma_small(0);
+    mfma_big(0);
+    mfma_small(1);
+    __builtin_amdgcn_s_setprio(0);
+    if (kt == 0) lstore(buf ^ 1, kt + 1, ra0[1], ra1[1], rb[1]);
+    else lstore(buf ^ 1, kt + 1, ra0[0], ra1[0], rb[0]);
+    __syncthreads();
+    ldfrag(0, buf ^ 1, 0);
+    mfma_big(1);
+  }
+  {
+    const int buf = (KT - 1) & 1;
+    ldfrag(1, buf, 1);
+    mfma_small(0);
+    mfma_big(0);
+    mfma_small(1);
+    mfma_big(1);
+    __syncthreads();
+  }
+#endif
 
   // ---- epilogue: one wave row (64 rows) at a time through LDS, 16 bytes per lane out
   constexpr int EP = BN + 4;
