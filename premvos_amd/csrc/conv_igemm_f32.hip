@@ -297,7 +297,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
     ldfrag(0, 0, 0);
     auto stage = [&](const int kt, auto plain_tag) {
       const int buf = kt & 1;
-      // (requesting a stage earlier -- right behind the previous barrier -- measured 1.3 % SLOWER)
+      // (requesting a stage earlier -- right behind the previous barrier -- measured 1.3 % slower with the predicated requests and
+      //  4 % slower with the plain ones; sunk to right before the ds_write: 1.7 % slower)
       if constexpr (decltype(plain_tag)::value) {
         gload_plain(kt_begin + kt + 1);
 #ifndef PV_DBG_NOPIN_GLOAD
