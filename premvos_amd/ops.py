@@ -541,6 +541,7 @@ def autotune(descs, device="cuda", reps: int = 4):
     mode = os.environ.get("PREMVOS_AUTOTUNE", "1")
     if mode == "0" or not torch.cuda.is_available():
         return
+    reps = int(os.environ.get("PREMVOS_AUTOTUNE_REPS", reps))      # launches per timing burst (tools/make_tune_table.py --reps)
     force = os.environ.get("PREMVOS_FORCE_KERNEL")          # diagnostics (tests/test_gpu_error_budget.py): every layer that CAN
     if force:                                                # run on this family does, whatever the table says
         fam = {"igemm": 0, "direct": 1, "wino": 2, "wino_fused": 3, "wino4": 4}[force]

@@ -27,6 +27,8 @@ os.environ["PREMVOS_AUTOTUNE"] = "polish" if POLISH else "full"
 if not POLISH:
     os.environ["PREMVOS_TUNE_TABLE"] = "0"
 os.environ.pop("PREMVOS_TUNE_CACHE", None)
+if "--reps" in sys.argv:               # launches per timing burst of a full exploration (default 4: ~1 % noise between near-equal
+    os.environ["PREMVOS_AUTOTUNE_REPS"] = sys.argv[sys.argv.index("--reps") + 1]      # configurations; 16 takes ~4x as long)
 
 import torch  # noqa: E402
 
@@ -38,6 +40,7 @@ def main():
     ap.add_argument("--out", default=ops.TUNE_TABLE)
     ap.add_argument("--with-1080p", action="store_true")
     ap.add_argument("--quick", action="store_true", help="bench shapes only")
+    ap.add_argument("--reps", type=int, default=4, help="launches per timing burst of a full exploration")
     ap.add_argument("--polish", action="store_true", help="start from the shipped table; re-time only order-neutral knobs (12 x 3 "
                     "repetitions), replace an entry when another block / stage depth is >= 1.5 %% faster; results do not change")
     a = ap.parse_args()
