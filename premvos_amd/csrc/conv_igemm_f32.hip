@@ -42,8 +42,11 @@ constexpr int BK = 16;           // k granularity of the packed weights (k_pad %
 // PW: pointwise layers (1x1 taps, no padding; any stride): the gather address of an A row is a fixed pixel base + k, so
 // the per-stage tap bookkeeping and 64-bit address arithmetic of the general path drop out (most ResNet / Xception
 // layers; the scalar+vector work between the barrier and the first MFMA of a stage was ~15 % of a stage).
+#ifndef PV_OCC128
+#define PV_OCC128 3      // workgroups per CU the 128x128 tile is compiled for (developer builds: -DPV_OCC128=4)
+#endif
 template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16, bool PW = false>
-__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) ? 3 : 1) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
+__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) ? PV_OCC128 : 1) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
