@@ -353,3 +353,44 @@ def test_conv2d_direct_kernel_for_one_or_two_output_channels(case):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert (outs[0].double() - ref).abs().max().item() < 2e-4
     assert (outs[0] - outs[3]).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pointwise_conv_interior_fast_path_boundaries(seed):
+    """Round 3: interior stages of interior tiles of 1x1 layers request their operands with plain (unpredicated) loads and the
+    K loop keeps two fragment sets.  Random shapes around every boundary of that path -- K a multiple of the stage depth or not,
+    cin_pad < / = / > (KT - 1) * KB, ragged last M tile, ragged / narrow last column tile, stride 2, k-slices (kt_begin > 0), tail
+    split, every tile -- against the fp64 convolution, and bit-identical across tiles (same k order per output)."""
+    ops = _ops()
+    rng = np.random.default_rng(1000 + seed)
+    cin = int(rng.choice([4, 12, 16, 20, 31, 32, 36, 64, 100, 128, 132, 260, 728]))
+    cout = int(rng.choice([32, 48, 88, 96, 128, 130, 200, 256, 728]))
+    n, h, w = int(rng.integers(1, 4)), int(rng.integers(9, 40)), int(rng.integers(9, 40))
+    stride = int(rng.choice([1, 1, 2]))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=stride))
+    ho, wo = ref.shape[2:]
+    xin, pk = _to_nhwc(x, ops), ops.pack_conv(wt, b)
+    outs = {}
+    for bm, bn in ((128, 128), (64, 64), (128, 64), (64, 128), (128, 32)):
+        if bn == 32 and cout > 32:
+            continue
+        for sk, tail in ((-1, (0, 0)), (2, (0, 0)), (-1, (1, 2))):
+            if sk > 0 and pk.k_pad < 64:
+                continue
+            out = ops.NHWC.alloc(n, ho, wo, cout)
+            d = ops.conv_desc(xin, pk, out, stride=(stride, stride), act=ops.ACT_RELU, tile_hint=(bm << 16) | bn, stage_k=16, split_k=sk)
+            d.tail_m_tiles, d.tail_split_k = tail
+            ws = torch.empty(max(ops.workspace_bytes(d) // 4, 1), dtype=torch.float32, device="cuda")
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+            ops.run_desc(d)
+            torch.cuda.synchronize()
+            got = out.torch().cpu()
+            assert (got.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (bm, bn, sk, tail)
+            outs[(bm, bn, sk, tail)] = got
+    for key, got in outs.items():
+        if key[2] == -1 and key[3] == (0, 0):
+            assert torch.equal(got, outs[[k for k in outs if k[2] == -1 and k[3] == (0, 0)][0]]), key      # tiles: order-neutral
