@@ -148,6 +148,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
   __syncthreads();
 
   const int frag_off = (lane & 31) * RSB + (lane >> 5) * 16;   // 8 consecutive k (16 B) of row lane&31
+#ifdef PV_DBG_BF16_OLDLOOP       // developer A/B builds: fragments read right before their MFMAs, everywhere
+  constexpr bool FRAG_PF = false;
+#else
+  // bf16x3 only: measured +2.5 % on the mixed-bf16x3 pipeline, -8 % on mixed-bf16 (one MFMA per product: a block is too short)
+  constexpr bool FRAG_PF = NPASS == 3 && (KB / 16) % 2 == 0;      // (a 16-deep stage is a single block: nothing to alternate)
+#endif
+  if constexpr (!FRAG_PF) {
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < KT) gload(kt_begin + kt + 1);
@@ -182,6 +189,67 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(const pre
     }
     if (kt + 1 < KT) lstore(buf ^ 1);
     __syncthreads();
+  }
+
+  } else {
+  // The loop of conv_igemm_f32.hip (late round 3): two fragment sets -- the LDS reads of the next 16-deep block are in flight
+  // under the current block's MFMAs, the first block of the next stage is requested right behind the barrier -- and a raised
+  // issue priority over the MFMA run.  Same products in the same order.
+  constexpr int S = KB / 16;
+  bf16x8 ah[2][MT], al[2][MT], bh[2][NTL], bl[2][NTL];
+  auto ldfrag = [&](const int set, const int buf, const int blk) {
+    const char* base = lds + buf * BUF_BYTES;
+    const char* a_hi = base + wm0 * RSB + frag_off + blk * 32;
+    const char* b_hi = base + PARTS * PART_BYTES_A + wn0 * RSB + frag_off + blk * 32;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      ah[set][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_hi + mi * 32 * RSB));
+      if constexpr (NPASS == 3) al[set][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_hi + PART_BYTES_A + mi * 32 * RSB));
+    }
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni) {
+      bh[set][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b_hi + ni * 32 * RSB));
+      if constexpr (NPASS == 3) bl[set][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b_hi + PART_BYTES_B + ni * 32 * RSB));
+    }
+  };
+  auto mfma_rows = [&](const int set, const int mi0, const int mi1) {
+#pragma unroll
+    for (int mi = mi0; mi < mi1; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) {
+        if constexpr (NPASS == 3) {      // small cross terms first, then the leading term
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][mi], bh[set][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][mi], bl[set][ni], acc[mi][ni], 0, 0, 0);
+        }
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][mi], bh[set][ni], acc[mi][ni], 0, 0, 0);
+      }
+  };
+  ldfrag(0, 0, 0);
+  for (int kt = 0; kt + 1 < KT; ++kt) {
+    const int buf = kt & 1;
+    gload(kt_begin + kt + 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int blk = 0; blk + 1 < S; ++blk) {
+      ldfrag((blk + 1) & 1, buf, blk + 1);
+      mfma_rows(blk & 1, 0, MT);
+    }
+    mfma_rows((S - 1) & 1, 0, MT - 1);
+    __builtin_amdgcn_s_setprio(0);
+    lstore(buf ^ 1);
+    __syncthreads();
+    ldfrag(0, buf ^ 1, 0);
+    mfma_rows((S - 1) & 1, MT - 1, MT);
+  }
+  {
+    const int buf = (KT - 1) & 1;
+#pragma unroll
+    for (int blk = 0; blk < S; ++blk) {
+      if (blk + 1 < S) ldfrag((blk + 1) & 1, buf, blk + 1);
+      mfma_rows(blk & 1, 0, MT);
+    }
+    __syncthreads();
+  }
   }
 
   if constexpr (SPLITK) {
