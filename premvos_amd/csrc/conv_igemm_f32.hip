@@ -467,6 +467,46 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
         }
         __syncthreads();
         constexpr int C4 = BN / 4, UNITS = WTM * C4;
+#ifndef PV_DBG_OLDEPI
+        if constexpr (UNITS % NT == 0 && NT % C4 == 0) {
+          // Every unit of a thread has the same four columns (NT is a multiple of the units per row): the bias is one request, and
+          // ALL the residual requests of the pass go out before anything waits for one -- written per unit under `if (m < M && ...)`
+          // hipcc emitted one exec-masked block per unit with `s_waitcnt vmcnt(0)` behind each load (late round 3; rows / columns
+          // past the tensor are requested at a clamped address and masked at the store).  Same sums in the same order.
+          constexpr int UPT = UNITS / NT, RSTEP = NT / C4;
+          const int c4 = tid % C4, row0 = tid / C4, col = n0 + c4 * 4;
+          const bool col_ok = col < p.cout;
+          const int colc = col_ok ? col : 0;
+          const float4 bv = p.bias != nullptr ? premvos::ld4(p.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 rv[UPT];
+          if (p.res != nullptr) {
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+              int m = m0 + wr * WTM + row0 + i * RSTEP;
+              m = m < M ? m : M - 1;
+              rv[i] = premvos::ld4(p.res + (long)m * p.res_ps + colc);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < UPT; ++i) {
+            const int row = row0 + i * RSTEP, m = m0 + wr * WTM + row;
+            float4 v = *reinterpret_cast<const float4*>(&stg[row * EP + c4 * 4]);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.res != nullptr) { v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w; }
+            if (p.act == PREMVOS_ACT_RELU) {
+              v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            } else if (p.act == PREMVOS_ACT_LEAKY) {
+              v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+              v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+            } else if (p.act == PREMVOS_ACT_SIGMOID) {
+              v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+            }
+            if (m < M && col_ok) *reinterpret_cast<float4*>(p.out + (long)m * p.out_ps + col) = v;
+          }
+          if (wr + 1 < WM) __syncthreads();
+          continue;
+        }
+#endif
 #pragma unroll
         for (int u = tid; u < UNITS; u += NT) {
           const int row = u / C4, c4 = u - row * C4;
@@ -587,6 +627,8 @@ bool conv_wino_fused_applicable(const premvos_conv_desc& d);
 bool conv_wino4_applicable(const premvos_conv_desc& d);       // conv_wino4_f32.hip
 long conv_wino4_workspace_bytes(const premvos_conv_desc& d);
 int conv_wino4(const premvos_conv_desc& d, hipStream_t s);
+bool conv_stream_applicable(const premvos_conv_desc& d);      // conv_stream_f32.hip
+int conv_stream(const premvos_conv_desc& d, hipStream_t s);
 bool conv_smalln_applicable(const premvos_conv_desc& d);      // conv_smalln_f32.hip
 int conv_smalln(const premvos_conv_desc& d, hipStream_t s);
 int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin) {
@@ -791,6 +833,11 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
                "padding (= the dilation for atrous layers) and packed filter transforms (wgt_wino)");
     return premvos::conv_wino_fused(d, s);
   }
+  if (d.tile_hint == 5) {      // short-K pointwise layers: persistent workgroups, weights resident in LDS (conv_stream_f32.hip); same sums
+    PV_REQUIRE(premvos::conv_stream_applicable(d), "conv2d: the streaming pointwise kernel needs a 1x1 / stride 1 fp32 layer with cin = 64 or 128 "
+               "(= k_pad), cout %% 128 == 0 (<= 512) and 16-byte aligned pixels");
+    return premvos::conv_stream(d, s);
+  }
   // 1- and 2-channel heads: per-pixel dot products, not GEMM tiles (tile_hint 0 = auto, 1 = forced; any other hint
   // keeps them on the MFMA kernel, which is what the autotuner compares against)
   if ((d.tile_hint == 0 || d.tile_hint == 1) && premvos::conv_smalln_applicable(d)) return premvos::conv_smalln(d, s);
@@ -825,6 +872,7 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   if (dp->tile_hint == 2) return premvos::conv_wino_applicable(*dp) ? premvos::conv_wino_workspace_bytes(*dp) : 0;
   if (dp->tile_hint == 3) return 0;
   if (dp->tile_hint == 4) return premvos::conv_wino4_applicable(*dp) ? premvos::conv_wino4_workspace_bytes(*dp) : 0;
+  if (dp->tile_hint == 5) return 0;
   if ((dp->tile_hint == 0 || dp->tile_hint == 1) && premvos::conv_smalln_applicable(*dp)) return 0;
   int bm, bn;
   pick_tile(*dp, &bm, &bn);

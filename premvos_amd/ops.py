@@ -286,6 +286,14 @@ def wino_atrous_applicable(d: ConvDesc) -> bool:
         and d.out_mode == OUT_NHWC and d.cout % 4 == 0 and (d.pt, d.pl) == (d.dh, d.dw) and (d.ho, d.wo) == (d.h, d.w)
 
 
+def stream_applicable(d: ConvDesc) -> bool:
+    """Mirror of premvos::conv_stream_applicable: 1x1 / stride 1 fp32 layers with cin = 64 or 128 (= k_pad) and cout % 128 == 0."""
+    return d.precision == _lib.PREC_F32 and (d.kh, d.kw, d.sh, d.sw, d.pt, d.pl) == (1, 1, 1, 1, 0, 0) and d.ho == d.h and d.wo == d.w \
+        and d.out_mode == OUT_NHWC and d.k_pad in (64, 128) and d.cin_pad == d.k_pad and d.cout % 128 == 0 and d.cout <= 512 \
+        and d.in_ps % 4 == 0 and d.out_ps % 4 == 0 and (not d.res or d.res_ps % 4 == 0) and d.act in (ACT_NONE, ACT_RELU, ACT_LEAKY) \
+        and (d.inp or 0) % 16 == 0 and (d.out or 0) % 16 == 0 and (d.res or 0) % 16 == 0
+
+
 def _candidates(d: ConvDesc):
     m = d.n * d.ho * d.wo
     if d.cout <= 32:
@@ -318,6 +326,8 @@ def _candidates(d: ConvDesc):
         mt4 = d.n * -(-d.ho // 4) * -(-d.wo // 4)
         if 36 * mt4 * (_r(d.cin_pad, 16) + _r(d.cout, 128)) * 4 <= WINO4_MAX_WS:
             out.extend((4, v, -1, 0, 0) for v in (0, 64, 16, 80))     # GEMM block: 128 / 64 tile rows x 32- / 16-deep stages
+    if stream_applicable(d):
+        out.append((5, 0, -1, 0, 0))               # tile_hint 5 = short-K streaming pointwise kernel (csrc/conv_stream_f32.hip): same sums
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((256, 128), (128, 128), (128, 64), (64, 128))) else [16]
@@ -409,6 +419,8 @@ def numerics_key(d: ConvDesc, cand):
     hint, st, sk, tail_rows, ts = cand
     if hint in (1, 2, 3, 4):
         return (hint,)
+    if hint == 5:                                # the streaming pointwise kernel adds the products in the implicit GEMM's order
+        return (0, None, None)
     bm = hint >> 16
     m = d.n * d.ho * d.wo
     st = st or 16

@@ -37,7 +37,9 @@ def test_shipped_table_parses_and_holds_legal_configurations():
             assert (hint >> 16, hint & 0xFFFF) in {(256, 128), (128, 128), (128, 96), (128, 64), (128, 32), (64, 128), (64, 64), (64, 32)}
             assert choice[1] in (16, 32)
         ops.numerics_key(d, tuple(choice))                                   # defined for every entry
-    assert fams == {0, 1, 2, 3, 4}
+        if hint == 5:                                                        # an order-neutral stand-in for the implicit GEMM
+            assert ops.numerics_key(d, tuple(choice)) == (0, None, None) and d.k_pad in (64, 128) and d.cout % 128 == 0
+    assert fams == {0, 1, 2, 3, 4, 5}           # implicit GEMM, direct, F(2x2) slab / slab-free, F(4x4), short-K streaming pointwise
 
 
 def test_rule_choice_is_a_function_of_the_signature_only():

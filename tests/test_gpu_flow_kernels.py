@@ -394,3 +394,41 @@ def test_pointwise_conv_interior_fast_path_boundaries(seed):
     for key, got in outs.items():
         if key[2] == -1 and key[3] == (0, 0):
             assert torch.equal(got, outs[[k for k in outs if k[2] == -1 and k[3] == (0, 0)][0]]), key      # tiles: order-neutral
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w,res,act", [(64, 128, 2, 37, 41, False, "relu"), (64, 256, 1, 50, 50, True, "relu"),
+                                                    (128, 128, 3, 19, 23, True, "none"), (128, 512, 1, 31, 17, True, "relu"),
+                                                    (128, 256, 1, 5, 7, False, "leaky"), (64, 128, 1, 300, 301, True, "relu")])
+def test_streaming_pointwise_kernel_is_bit_identical_to_the_implicit_gemm(cin, cout, n, h, w, res, act):
+    """tile_hint 5 (csrc/conv_stream_f32.hip: persistent workgroups, weights resident in LDS, no workgroup barrier in the loop) adds
+    the products of an output in the implicit GEMM's order: the same bits, whatever M (ragged last step, fewer steps than
+    workgroups), with / without residual, per activation; and it refuses layers it does not cover."""
+    ops = _ops()
+    from premvos_amd import _lib
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5
+    b = torch.randn((cout,), generator=g)
+    r = torch.randn((n, cout, h, w), generator=g) if res else None
+    a = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY}[act]
+    xin, pk, rr = _to_nhwc(x, ops), ops.pack_conv(wt, b), (_to_nhwc(r, ops) if res else None)
+    outs = []
+    for hint in ((128 << 16) | 128, 5, (64 << 16) | 64):
+        out = ops.NHWC.alloc(n, h, w, cout)
+        d = ops.conv_desc(xin, pk, out, act=a, res=rr, tile_hint=hint, stage_k=16, split_k=-1)
+        assert ops.stream_applicable(d)
+        assert ops.numerics_key(d, (hint, 16, -1, 0, 0)) == ops.numerics_key(d, (5, 0, -1, 0, 0))
+        ops.run_desc(d)
+        torch.cuda.synchronize()
+        outs.append(out.torch().cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = F.conv2d(x.double(), wt.double(), b.double())
+    ref = ref + r.double() if res else ref
+    ref = {"none": lambda v: v, "relu": F.relu, "leaky": lambda v: F.leaky_relu(v, 0.1)}[act](ref)
+    assert (outs[1].double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # not covered: stride 2, cout not a multiple of 128
+    wt2 = torch.randn((96, cin, 1, 1), generator=g)
+    d = ops.conv_desc(xin, ops.pack_conv(wt2, None), ops.NHWC.alloc(n, h, w, 96), tile_hint=5)
+    assert not ops.stream_applicable(d)
+    with pytest.raises(_lib.PremvosError, match="streaming pointwise"):
+        ops.run_desc(d)
