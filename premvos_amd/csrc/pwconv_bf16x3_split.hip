@@ -271,27 +271,36 @@ __global__ __launch_bounds__(NT) void pwconv_bf16x3_split_kernel(const PwArgs p)
     }
     __syncthreads();
     if (wide) {
-      constexpr int C4 = BN / 4, UNITS = 64 * C4;
-      for (int u = tid; u < UNITS; u += NT) {
-        const int row = u / C4, c4 = u - row * C4;
+      // one bias request per thread (its units share their four columns) and all residual requests of the pass in flight before
+      // anything waits for one (conv_igemm_f32.hip, late round 3); rows / columns past the tensor: clamped address, masked store
+      constexpr int C4 = BN / 4, UPT = 64 * C4 / NT, RSTEP = NT / C4;
+      const int c4 = tid % C4, row0 = tid / C4, col = n0 + c4 * 4;
+      const bool col_ok = col < p.cout;
+      const int colc = col_ok ? col : 0;
+      const float4 bv = p.bias != nullptr ? premvos::ld4(p.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 rv[UPT];
+      if (p.res != nullptr) {
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+          long m = m0 + wr * 64 + row0 + i * RSTEP;
+          m = m < p.m ? m : p.m - 1;
+          rv[i] = premvos::ld4(p.res + m * p.res_ps + colc);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < UPT; ++i) {
+        const int row = row0 + i * RSTEP;
         const long m = m0 + wr * 64 + row;
-        const int col = n0 + c4 * 4;
-        if (m < p.m && col < p.cout) {
-          float4 v = *reinterpret_cast<const float4*>(&stg[row * EP + c4 * 4]);
-          if (p.bias != nullptr) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-          }
-          if (p.res != nullptr) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.res + m * p.res_ps + col);
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-          }
-          if (p.act == PREMVOS_ACT_RELU) {
-            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-          } else if (p.act == PREMVOS_ACT_LEAKY) {
-            v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
-            v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
-          }
+        float4 v = *reinterpret_cast<const float4*>(&stg[row * EP + c4 * 4]);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (p.res != nullptr) { v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w; }
+        if (p.act == PREMVOS_ACT_RELU) {
+          v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        } else if (p.act == PREMVOS_ACT_LEAKY) {
+          v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+          v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+        }
+        if (m < p.m && col_ok) {
           *reinterpret_cast<float4*>(p.out + m * p.out_ps + col) = v;
           if (p.out_split != nullptr) *reinterpret_cast<float4*>(p.out_split + m * p.out_split_ps + col) = premvos::split_bf16_group(v);
         }
