@@ -437,6 +437,64 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
       return;
     }
 #endif
+#ifndef PV_DBG_NOWAVEEPI
+    // Wave-private epilogue (late round 3, after conv_stream_f32.hip): every wave stages ITS 32-row slices through its own LDS
+    // block -- a wave's LDS instructions execute in order, so no barrier is needed between its writes and its reads -- instead of
+    // the workgroup staging one wave row at a time behind __syncthreads(): the four waves finish (and free their workgroup slot
+    // for the next tile) independently.  Where the blocks fit the operand buffers; not for the narrow layout.
+    constexpr int WSC = WTN + 4;                                 // staged row pitch of a wave's block (floats)
+    constexpr bool WAVE_EPI = (NT / 64) * 32 * WSC <= 2 * BUF && WTN % 16 == 0 && (WTN / 4) <= 64 && 64 % (WTN / 4) == 0;
+    if constexpr (WAVE_EPI) {
+      if (wide && !(NARROW_OK && narrow)) {
+        float* stg = lds_dyn + wave * (32 * WSC);
+        constexpr int WC4 = WTN / 4, RPP = 64 / WC4, UPT = 32 / RPP;      // 16-byte units per staged row; rows per pass of the wave
+        const int c4 = lane % WC4, r0 = lane / WC4, col = n0 + wn0 + c4 * 4;
+        const bool col_ok = col < p.cout;
+        const int colc = col_ok ? col : 0;
+        const float4 bv = p.bias != nullptr ? premvos::ld4(p.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (the K loop ends with a barrier: every wave is done reading the operand buffers)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int mbase = m0 + wm0 + mi * 32;
+          float4 rv[UPT];
+          if (p.res != nullptr) {
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+              int m = mbase + r0 + i * RPP;
+              m = m < M ? m : M - 1;
+              rv[i] = premvos::ld4(p.res + (long)m * p.res_ps + colc);
+            }
+          }
+#pragma unroll
+          for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              stg[row * WSC + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+            }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i = 0; i < UPT; ++i) {
+            const int row = r0 + i * RPP, m = mbase + row;
+            float4 v = *reinterpret_cast<const float4*>(&stg[row * WSC + c4 * 4]);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.res != nullptr) { v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w; }
+            if (p.act == PREMVOS_ACT_RELU) {
+              v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            } else if (p.act == PREMVOS_ACT_LEAKY) {
+              v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;
+              v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
+            } else if (p.act == PREMVOS_ACT_SIGMOID) {
+              v.x = 1.f / (1.f + expf(-v.x)); v.y = 1.f / (1.f + expf(-v.y)); v.z = 1.f / (1.f + expf(-v.z)); v.w = 1.f / (1.f + expf(-v.w));
+            }
+            if (m < M && col_ok) *reinterpret_cast<float4*>(p.out + (long)m * p.out_ps + col) = v;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        return;
+      }
+    }
+#endif
     if (wide) {                                                  // kernel-uniform
       float* stg = lds_dyn;
 #pragma unroll 1
