@@ -407,6 +407,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
     static_assert(WTM * EP <= 2 * BUF, "the staged wave row must fit the operand buffers");
     if (wide) {                                                  // kernel-uniform
       float* stg = lds_dyn;
+      // a thread's 16-byte units share their four columns when the thread count is a multiple of the units per row: ONE bias
+      // request per kernel instead of one (waited for on the spot) per unit (conv_igemm_f32.hip, late round 3)
+      constexpr bool BIAS_ONCE = NT % (BN / 4) == 0;
+      float4 bias_once = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (BIAS_ONCE) {
+        const int colb = n0 + (tid % (BN / 4)) * 4;
+        if (p.bias != nullptr && colb < p.cout) bias_once = premvos::ld4(p.bias + colb);
+      }
 #pragma unroll 1
       for (int wr = 0; wr < WM; ++wr)
 #pragma unroll
@@ -436,7 +444,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_fused_kernel(const premv
               if (oy >= p.ho || ox >= p.wo) continue;
               const long pix = ((long)n * p.ho + oy) * p.wo + ox;
               float4 v = *reinterpret_cast<const float4*>(&stg[row * EP + c4 * 4]);
-              if (p.bias != nullptr) {
+              if constexpr (BIAS_ONCE) {
+                v.x += bias_once.x; v.y += bias_once.y; v.z += bias_once.z; v.w += bias_once.w;
+              } else if (p.bias != nullptr) {
                 const float4 bb = *reinterpret_cast<const float4*>(p.bias + col);
                 v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
               }
