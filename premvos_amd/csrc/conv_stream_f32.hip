@@ -146,8 +146,12 @@ int launch(const premvos_conv_desc& d, hipStream_t s) {
   (void)attr_done;
   const long M = (long)d.n * d.ho * d.wo;
   const int m_steps = (int)((M + ROWS - 1) / ROWS), n_tiles = d.cout / BN;
-  int wgs = 256 / n_tiles;                                   // one persistent workgroup per CU, the column tiles side by side
-  while (wgs > 8 && wgs - 8 >= m_steps) wgs -= 8;            // (a multiple of 8: the XCD mapping in the kernel)
+  // one persistent workgroup per CU, the column tiles side by side.  The kernel's (XCD, column tile, row walker) mapping is a
+  // bijection only when the grid is a multiple of 8 * n_tiles: wgs is rounded DOWN to a multiple of 8 (cout = 384: 80 walkers x 3
+  // column tiles = 240 workgroups; 85 x 3 would leave rows of the third column tile uncomputed)
+  int wgs = (256 / n_tiles) & ~7;
+  if (wgs < 8) wgs = 8;
+  while (wgs > 8 && wgs - 8 >= m_steps) wgs -= 8;
   hipLaunchKernelGGL((conv_stream_f32_kernel<KG, ACT, HAS_RES>), dim3(wgs * n_tiles), dim3(NT), LDS_BYTES, s, d, m_steps, n_tiles);
   return premvos::check_launch("conv_stream_f32");
 }

@@ -27,12 +27,34 @@ A = TypeVar("A")
 B = TypeVar("B")
 
 
+def host_budget(cpus: int = None, world: int = None) -> dict:
+    """Host threads of ONE rank of a one-process-per-GPU job, sized from the threads the node has per rank
+    (``os.cpu_count() // LOCAL_WORLD_SIZE``; the ranks of a node share its cores).  A rank of the streaming driver runs
+    main (chunking + GPU JPEG finish) + 3 stage threads + ``refine_lanes`` refinement threads + the proposal joiner + the
+    writer, and ``decode`` decode-ahead threads on top (Huffman decode / PIL, GIL released).  Most of these block on the GPU or
+    on files, so a rank may hold twice its share of hardware threads: with >= 6 per rank the defaults of rounds 2-3 stand (4
+    decode threads, 2 refinement lanes = 12 threads per rank, 96 on an 8-GPU node of 256 threads); below that the decode pool
+    shrinks first (to 1), then the second refinement lane goes.  Explicit
+    PREMVOS_IO_THREADS / PREMVOS_IO_LANES / PREMVOS_STREAM_REFINE_LANES always win."""
+    cpus = (os.cpu_count() or 1) if cpus is None else cpus
+    if world is None:
+        world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    per_rank = max(1, cpus // max(world, 1))
+    budget = 2 * per_rank                         # the stage / lane threads spend most of their time blocked on the GPU or on files
+    fixed = 6                                     # main, flow, proposals x2, joiner, writer
+    lanes = 2 if budget >= fixed + 2 + 1 else 1
+    decode = max(1, min(4, budget - fixed - lanes))
+    return {"threads_per_rank": per_rank, "decode": decode, "refine_lanes": lanes, "total": fixed + lanes + decode}
+
+
 def io_threads() -> int:
-    return max(0, int(os.environ.get("PREMVOS_IO_THREADS", "4")))
+    v = os.environ.get("PREMVOS_IO_THREADS")
+    return max(0, int(v)) if v is not None else host_budget()["decode"]
 
 
 def io_lanes() -> int:
-    return max(1, int(os.environ.get("PREMVOS_IO_LANES", "2")))
+    v = os.environ.get("PREMVOS_IO_LANES")
+    return max(1, int(v)) if v is not None else host_budget()["refine_lanes"]
 
 
 def prefetch(jobs: Iterable[A], load: Callable[[A], B], workers: int = None, depth: int = None) -> Iterator[B]:

@@ -462,6 +462,25 @@ def rule_choice(d: ConvDesc):
     return ((bm << 16) | bn, 16, sk, 0, 0)
 
 
+def _entry_for(d: ConvDesc):
+    """The table / cache entry of this descriptor's signature -- unless THIS descriptor cannot run it.  ``_sig`` leaves out what
+    only some kernels care about (pointer alignment of a channel window, the residual's pixel stride, the 2^30-element limit of the
+    slab-free Winograd kernel): a layer with the signature of a tabled one but e.g. an unaligned slice falls back to the implicit
+    GEMM -- for the streaming kernel (hint 5) with the SAME sums (same numerics_key), otherwise to the closed-form rule with the
+    Winograd candidates withheld -- instead of failing in the library's argument check at launch time."""
+    cand = _TUNE_CACHE[_sig(d)]
+    hint = cand[0]
+    if hint == 5 and not stream_applicable(d):
+        return ((128 << 16) | 128, 16, -1, 0, 0)
+    if hint in (2, 3, 4) and cand not in _candidates(d):
+        w2, w4, d.wgt_wino, d.wgt_wino4 = d.wgt_wino, d.wgt_wino4, None, None
+        try:
+            return rule_choice(d)
+        finally:
+            d.wgt_wino, d.wgt_wino4 = w2, w4
+    return cand
+
+
 def _time_cands(d: ConvDesc, cands, lib, stream, reps):
     best, best_t = None, float("inf")
     for cand in cands:
@@ -615,7 +634,7 @@ def autotune(descs, device="cuda", reps: int = 4):
             if cache_file and os.environ.get("RANK", "0") == "0":
                 save_tune_cache(cache_file)
         for d in descs:
-            d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = _TUNE_CACHE[_sig(d)]
+            d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = _entry_for(d)
 
 
 def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):

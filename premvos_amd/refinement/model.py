@@ -335,11 +335,14 @@ class RefinementNet:
                     p.capture()
                 with self._plans_lock:
                     self._plans[key] = p
-                    # every plan holds a full Xception activation set: evict the least recently used one OF THIS LANE first
-                    # (the other lane's plan may be executing on its own thread right now), any lane only beyond that
-                    while len(self._plans) > self.max_plans:
+                    # every plan holds a full Xception activation set: evict the least recently used one OF THIS LANE (another lane's
+                    # plan may be executing on its own thread right now) -- the bound is PER LANE (max_plans each): two lanes over varying proposal counts must not evict, rebuild and
+                    # re-tune each other's activation sets
+                    while True:
                         mine = [k for k in self._plans if k[4] == lane and k != key]
-                        self._plans.pop(mine[0] if mine else next(k for k in self._plans if k != key))
+                        if len(mine) < self.max_plans:
+                            break
+                        self._plans.pop(mine[0])
         return p
 
     def refine(self, frame_rgb: torch.Tensor, boxes_y0x0y1x1: torch.Tensor, max_boxes: Optional[int] = None,

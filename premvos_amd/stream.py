@@ -81,14 +81,15 @@ class StreamPipeline:
         self.engine = rd.RefinementEngine(rd.RefinementNet(rw, rd.infer_num_middle(rw), use_graph=False))
         # refinement is half of a frame's FLOPs and has the longest host tail (D2H of masks' run boundaries): two lanes = two host
         # threads, each with its own stream and workspace of the net, take the chunks in turn (PREMVOS_STREAM_REFINE_LANES)
-        self.refine_lanes = max(1, int(os.environ.get("PREMVOS_STREAM_REFINE_LANES", "2")))
+        # -- sized from the host threads this rank may use (io_pipeline.host_budget: cpu_count // ranks of the node)
+        self.refine_lanes = max(1, int(os.environ.get("PREMVOS_STREAM_REFINE_LANES", iop.host_budget()["refine_lanes"])))
         self.streams = {k: torch.cuda.Stream(device=self.dev)
                         for k in ["flow", "prop0", "prop1", "decode"] + [f"ref{i}" for i in range(self.refine_lanes)]}
         self.flow_stages, self.prop_stages = {}, {}
 
     # ---- the stage bodies (each runs on its own host thread and HIP stream) ----------------------------------------
     def _flow(self, chunk, writer):                 # chunk: (seq, names, frames [n,H,W,3] uint8 RGB, next frame or None)
-        from .flow.driver import FlowStage, writeFlowFile
+        from .flow.driver import FlowStage
         seq, names, frames, nxt = chunk
         second = list(frames[1:]) + ([nxt] if nxt is not None else [])
         n = len(second)                             # pairs in this chunk (the last frame of a video has none)
@@ -100,10 +101,8 @@ class StreamPipeline:
             im1 = jpeg.stack_frames(frames[:n], self.dev)
             im2 = jpeg.stack_frames(second, self.dev)
             flo = self.flow_stages[n].run(im1, im2).cpu().numpy()
-        for k in range(n):
-            fn = os.path.join(self.out, "flow", seq, names[k] + ".flo")
-            os.makedirs(os.path.dirname(fn), exist_ok=True)
-            writer.submit(writeFlowFile, fn, flo[k])
+        for k in range(n):           # (the directory is made by whoever WRITES the file: with --gather that is the merge rank only)
+            writer.submit(_write_flo, os.path.join(self.out, "flow", seq, names[k] + ".flo"), flo[k])
         return None
 
     def _proposals(self, which, chunk, writer):
@@ -282,6 +281,12 @@ def _dump_json(fn, obj):
         json.dump(obj, f)
 
 
+def _write_flo(fn, uv):
+    from .flow.driver import writeFlowFile
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    writeFlowFile(fn, uv)
+
+
 def _write_bytes(fn, data: bytes):
     os.makedirs(os.path.dirname(fn), exist_ok=True)
     with open(fn, "wb") as f:
@@ -302,8 +307,8 @@ class GatherWriter:
         self._lock = threading.Lock()
 
     def submit(self, fn, path, obj):
-        from .flow.driver import flo_bytes, writeFlowFile
-        data = flo_bytes(obj) if fn is writeFlowFile else json.dumps(obj).encode() if fn is _dump_json else None
+        from .flow.driver import flo_bytes
+        data = flo_bytes(obj) if fn is _write_flo else json.dumps(obj).encode() if fn is _dump_json else None
         if data is None:
             raise TypeError(f"GatherWriter cannot serialise the payload of {fn}")
         with self._lock:
@@ -414,7 +419,10 @@ def run(root: str, seq_file: str, flow_weights: str, general_weights: str, speci
         dist.all_reduce(t)                                   # also the job's final barrier: every file is on disk after it
         total = int(t.item())
     if rank == 0:
-        # which configurations computed these files (ops.tune_info): the shipped table's hash + how many signatures it lacked
+        # which configurations computed these files (ops.tune_info): the shipped table's hash + how many signatures it lacked.
+        # The manifest records the rank count and the shard plan, so it differs between a 1-rank and an N-rank job BY DESIGN: it
+        # lives NEXT TO the stage tree (<out>/../premvos_amd_manifest.json), never inside `out` -- the tree the byte-identity
+        # promise (and tests/test_gpu_plumbing.py::_same_tree) covers is `out` = output/intermediate, what ReID / MergeTrack read
         _dump_json(os.path.join(os.path.dirname(out.rstrip("/")) or ".", "premvos_amd_manifest.json"),
                    {"frames": total, "ranks": world, "chunk": batch, "sharding": shard,
                     "shards": [[[folders[v], a, b] for v, a, b in p] for p in plans], "conv_configurations": ops.tune_info()})

@@ -90,7 +90,7 @@ def _parse_shape(buf: bytes) -> List[int]:
 
 
 def _parse_entry(buf: bytes) -> dict:
-    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "slices": False}
+    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "slices": []}
     for f, _, v in _pb_fields(buf):
         if f == 1:
             e["dtype"] = v
@@ -104,9 +104,46 @@ def _parse_entry(buf: bytes) -> dict:
             e["size"] = v
         elif f == 6:
             e["crc32c"] = struct.unpack("<I", v)[0]
-        elif f == 7:
-            e["slices"] = True
+        elif f == 7:                                 # TensorSliceProto: repeated Extent {start = 1, length = 2 (absent = all)}
+            ext = []
+            for f2, _, v2 in _pb_fields(v):
+                if f2 == 1:
+                    start, length = 0, -1
+                    for f3, _, v3 in _pb_fields(v2):
+                        if f3 == 1:
+                            start = v3
+                        elif f3 == 2:
+                            length = v3
+                    ext.append((start, length))
+            e["slices"].append(ext)
     return e
+
+
+def _oc_signed(v: int) -> bytes:
+    """OrderedCode::WriteSignedNumIncreasing (tensorflow/core/lib/strings/ordered_code.cc): n bytes hold 7n - 1 magnitude bits
+    behind a unary length header; one byte 0x80 ^ v for -64 <= v < 64."""
+    x = ~v if v < 0 else v
+    n = 1
+    while x >> (7 * n - 1):
+        n += 1
+    b = bytearray((v & ((1 << 80) - 1)).to_bytes(10, "big")[10 - n:])
+    hdr = (0xFF00 >> n) & 0xFF if n <= 8 else 0xFF
+    b[0] ^= hdr
+    if n == 9:
+        b[1] ^= 0x80
+    elif n == 10:
+        b[1] ^= 0xC0
+    return bytes(b)
+
+
+def _slice_key(name: bytes, extents) -> bytes:
+    """checkpoint::EncodeTensorNameSlice: the table key under which one partition of a partitioned variable is stored."""
+    esc = b"".join(b"\x00\xff" if c == 0 else b"\xff\x00" if c == 255 else bytes([c]) for c in name)
+    nd = len(extents)
+    key = b"\x00" + esc + b"\x00\x01" + (bytes([1, nd]) if nd else b"\x00")
+    for start, length in extents:
+        key += _oc_signed(start) + _oc_signed(length)
+    return key
 
 
 # --------------------------------------------------------------------------------------------------
@@ -239,17 +276,8 @@ def load_tf_checkpoint(prefix: str, verify: bool = True) -> Dict[str, np.ndarray
             raise ValueError("big-endian bundles are not supported")
     shards: Dict[int, np.memmap] = {}
     out: Dict[str, np.ndarray] = {}
-    for key, val in table.items():
-        if key == b"":
-            continue
-        e = _parse_entry(val)
-        if e["slices"]:
-            # a variable saved through a partitioner: its data lives under ordered-code slice keys, one per partition.  Neither
-            # tensorpack (proposal_net/train.py:655) nor the slim graph (Saver.py:33-48) of the reference partitions anything.
-            raise ValueError(f"{key!r}: the checkpoint stores this variable as partitioned slices (BundleEntryProto.slices); "
-                             f"re-save it unpartitioned -- the reference's graphs define no partitioner")
-        if e["dtype"] not in _DTYPES:
-            continue                                 # strings etc. (global_step is int64 and is kept)
+
+    def tensor(key: bytes, e: dict) -> np.ndarray:
         sid = e["shard_id"]
         if sid not in shards:
             fn = f"{prefix}.data-{sid:05d}-of-{num_shards:05d}"
@@ -264,7 +292,39 @@ def load_tf_checkpoint(prefix: str, verify: bool = True) -> Dict[str, np.ndarray
         raw = np.asarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
         if verify and e["crc32c"] is not None and _mask_crc(crc32c(raw.tobytes())) != e["crc32c"]:
             raise ValueError(f"{key!r}: tensor checksum mismatch")
-        out[key.decode()] = raw.view(_DTYPES[e["dtype"]]).reshape(e["shape"]).copy()
+        return raw.view(_DTYPES[e["dtype"]]).reshape(e["shape"]).copy()
+
+    for key, val in table.items():
+        if key == b"":
+            continue
+        e = _parse_entry(val)
+        if key[:1] == b"\x00":
+            continue                                 # an ordered-code slice key: read through its variable's entry below
+        if e["dtype"] not in _DTYPES:
+            continue                                 # strings etc. (global_step is int64 and is kept)
+        if e["slices"]:
+            # a variable saved through a partitioner (neither tensorpack, proposal_net/train.py:655, nor the slim graph, Saver.py:
+            # 33-48, of the reference defines one -- but tf.train.Saver writes them this way whenever a graph does): the full-name
+            # entry has the shape and the slice list, every partition is an entry of its own under an ordered-code key
+            full = np.zeros(e["shape"], dtype=_DTYPES[e["dtype"]])
+            covered = 0
+            for ext in e["slices"]:
+                sk = _slice_key(key, ext)
+                if sk not in table:
+                    raise ValueError(f"{key!r}: partition {ext} is listed in the variable's entry but has no slice entry in the index")
+                se = _parse_entry(table[sk])
+                idx = tuple(slice(st, None if ln < 0 else st + ln) for st, ln in ext)
+                part = tensor(key + b" " + repr(ext).encode(), se)
+                if full[idx].shape != part.shape:
+                    raise ValueError(f"{key!r}: partition {ext} has shape {list(part.shape)}, the variable's shape {e['shape']} needs "
+                                     f"{list(full[idx].shape)}")
+                full[idx] = part
+                covered += part.size
+            if covered != full.size:
+                raise ValueError(f"{key!r}: its partitions cover {covered} of {full.size} elements")
+            out[key.decode()] = full
+            continue
+        out[key.decode()] = tensor(key, e)
     return out
 
 

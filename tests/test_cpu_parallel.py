@@ -265,3 +265,137 @@ def test_stage_drivers_take_the_reference_slice_of_the_video_list(monkeypatch):
         monkeypatch.setenv("LOCAL_RANK", str(r))
         got.append(P.my_videos(vids))
     assert got == [vids[0:3], vids[3:5], vids[5:7]] and P.env_rank() == (3, 2, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world 8 (one node of MI355X): the same paths with ranks that own nothing
+def _spawn(target, world, *args, timeout=240):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=timeout)
+    for p in procs:
+        p.join(timeout=timeout)
+        assert p.exitcode == 0
+    return res
+
+
+def _strong_worker(rank, world, port, q, T, B):
+    """bench.py's strong-scaling step at world 8: ONE video of T frame pairs in chunks of B shared out by plan_shards; every rank
+    takes part in every round's gather, the ranks that own no chunk of the round send whatever they packed last (bench.py:381-387);
+    the merge rank takes a chunk from the rank the plan names."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P_, H, W = 3, 5, 7
+    x = P.ResultExchange(B, H, W, P_, "cpu", pack_bits=_np_pack_bits, unpack_bits=_np_unpack_bits)
+    plans = [P.plan_shards([T], world, r, B) for r in range(world)]
+    chunks = [[c0 // B for _, s0, e0 in p for c0 in range(s0, e0, B)] for p in plans]      # chunk ids per rank
+    rounds = max(len(c) for c in chunks)
+    ok = True
+    for step in range(2):                                  # two passes over the video: the slots come round again
+        last, slots = _fake_results(999, B, P_, H, W), []  # an idle rank's filler
+        for k in range(rounds):
+            if k < len(chunks[rank]):
+                last = _fake_results(1000 * step + chunks[rank][k], B, P_, H, W)
+            slots.append(x.exchange_async(last))
+        x.flush()
+        if rank == 0:                                      # the last `len(x._packed)` rounds are still in their slots
+            for k in range(max(0, rounds - 2), rounds):
+                for r in range(world):
+                    if k < len(chunks[r]):
+                        ref, u = _fake_results(1000 * step + chunks[r][k], B, P_, H, W), x.unpack(x.gathered_slot(slots[k])[r])
+                        ok = ok and all(torch.equal(u[key], ref[key]) for key in ref)
+    if rank == 0:
+        owners = sorted(c for cs in chunks for c in cs)
+        q.put((ok, owners, sum(1 for c in chunks if not c), rounds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,B,idle", [(13, 2, 1), (10, 2, 3), (40, 2, 0)])
+def test_result_exchange_async_world8_gloo_with_idle_ranks(T, B, idle):
+    ok, owners, n_idle, rounds = _spawn(_strong_worker, 8, T, B)
+    assert ok and owners == list(range(-(-T // B))) and n_idle == idle and rounds == -(-(-(-T // B)) // 8)
+
+
+def _gather_writer_worker(rank, world, port, q, root):
+    from premvos_amd import stream
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    gw = stream.GatherWriter(torch.device("cpu"))
+    written = 0
+    for item in range(3):                        # three shard items; ranks 2, 5 never have files, rank 7 only in item 1
+        if rank not in (2, 5) and (rank != 7 or item == 1):
+            gw.submit(stream._dump_json, os.path.join(root, f"json/r{rank}_{item}.json"), [{"bbox": [rank, item, 1.5, 2.5], "score": 0.5}])
+            gw.submit(stream._write_flo, os.path.join(root, f"flow/r{rank}_{item}.flo"),
+                      np.full((2, 3, 2), rank + 0.25 * item, np.float32))
+        written += gw.flush()                    # collective: every rank, every item, files or not
+    if rank == 0:
+        q.put(written)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_writer_flush_world8_with_empty_ranks(tmp_path):
+    import json
+    import numpy as np
+    from premvos_amd.flow.driver import readFlowFile
+    written = _spawn(_gather_writer_worker, 8, str(tmp_path))
+    ranks_items = [(r, i) for i in range(3) for r in range(8) if r not in (2, 5) and (r != 7 or i == 1)]
+    assert written == 2 * len(ranks_items) == len(list(tmp_path.rglob("*.*")))
+    for r, i in ranks_items:                     # only the merge rank created directories / files; every payload intact
+        assert json.load(open(tmp_path / "json" / f"r{r}_{i}.json")) == [{"bbox": [r, i, 1.5, 2.5], "score": 0.5}]
+        assert np.array_equal(readFlowFile(str(tmp_path / "flow" / f"r{r}_{i}.flo")), np.full((2, 3, 2), r + 0.25 * i, np.float32))
+
+
+def _shard8_worker(rank, world, port, q, counts, batch):
+    """plan_shards + iter_chunks at world 8 on a multi-video tree (fewer videos than ranks: frame ranges, rotated start rank)."""
+    import numpy as np
+    from premvos_amd import stream
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owned, pairs, sizes = [], [], []
+    for v, first, end in P.plan_shards(counts, world, rank, batch):
+        images = [f"/video{v}/{t:05d}.jpg" for t in range(counts[v])]
+        for names, frames, nxt in stream.iter_chunks(images, first, end, batch, lambda fn: np.full((2, 2, 3), int(os.path.basename(fn)[:5]), np.int32)):
+            ids = [int(f[0, 0, 0]) for f in frames]
+            owned += [(v, t) for t in ids]
+            sizes.append((v, len(ids)))
+            second = ids[1:] + ([int(nxt[0, 0, 0])] if nxt is not None else [])
+            pairs += [(v, a, b) for a, b in zip(ids, second)]
+    own = [None] * world
+    dist.all_gather_object(own, (owned, pairs, sizes))
+    if rank == 0:
+        q.put(own)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts,batch", [([13, 4, 7], 2), ([5], 8), ([70, 50, 30, 90, 20, 11, 64, 8, 3], 8)])
+def test_sharding_world8_gloo_ragged_videos(counts, batch):
+    own = _spawn(_shard8_worker, 8, counts, batch)
+    assert sorted(x for o, _, _ in own for x in o) == [(v, t) for v, n in enumerate(counts) for t in range(n)]
+    assert sorted(x for _, p, _ in own for x in p) == [(v, t, t + 1) for v, n in enumerate(counts) for t in range(n - 1)]
+    if len(counts) < 8:      # frame ranges: the chunks are exactly the ones a single rank forms
+        assert sorted(s for _, _, ss in own for s in ss) == sorted((v, c) for v, n in enumerate(counts)
+                                                                   for c in [batch] * (n // batch) + [n % batch] * bool(n % batch))
+    else:                    # whole videos per rank
+        assert all(len({v for v, _ in o}) >= 1 for o, _, _ in own) and sum(1 for o, _, _ in own if len({v for v, _ in o}) == 2) == 1
+
+
+def test_host_budget_is_sized_from_the_threads_per_rank():
+    from premvos_amd import io_pipeline as iop
+    assert iop.host_budget(256, 8) == {"threads_per_rank": 32, "decode": 4, "refine_lanes": 2, "total": 12}
+    assert iop.host_budget(32, 8)["decode"] == 1 and iop.host_budget(32, 8)["refine_lanes"] == 1
+    for cpus, world in ((256, 8), (64, 8), (16, 8), (8, 1)):
+        b = iop.host_budget(cpus, world)
+        assert b["total"] * world <= max(2 * cpus, 8 * world)          # never more than 2x the hardware threads (or the 8-thread floor)

@@ -182,3 +182,25 @@ def test_importers_ignore_optimizer_slots_and_bookkeeping_variables():
                "xception_65/entry_flow/conv1_1/weights/Adam_1": np.zeros((3, 3, 4, 32), np.float32),
                "xception_65/entry_flow/conv1_1/BatchNorm/beta/Adam": np.zeros((32,), np.float32), "beta1_power": np.array(0.9, np.float32)})
     assert sorted(W.refinement_weights_from_tf(tv)) == want
+
+
+def test_reader_on_a_bundle_assembled_by_an_independent_writer():
+    """tests/golden/bundle/ was hand-assembled from the published format by tools/make_golden_bundle.py, which shares no code with
+    premvos_amd/weights.py (own varints, bit-by-bit CRC-32C, own table builder with restart interval 16, shortened index
+    separators, ordered-code slice keys): two data shards, prefix-compressed keys over several blocks, an int64 scalar, an int32
+    matrix, a zero-size dimension and ONE PARTITIONED variable (64 + 6 rows; the 64 takes the two-byte signed ordered code)."""
+    import json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bundle")
+    got = W.load_tf_checkpoint(os.path.join(root, "golden"))
+    exp = json.load(open(os.path.join(root, "expected.json")))
+    assert set(got) == set(exp) and "fastrcnn/partitioned/W" in got
+    for k, v in exp.items():
+        a = np.array(v["values"], dtype=v["dtype"]).reshape(v["shape"])
+        assert got[k].dtype == a.dtype and got[k].shape == a.shape and np.array_equal(got[k], a), k
+    # the slice keys the reader derives are the ones the independent writer stored
+    table = W.read_table(os.path.join(root, "golden.index"))
+    assert W._slice_key(b"fastrcnn/partitioned/W", [(64, 6), (0, -1)]) in table
+    assert W._slice_key(b"fastrcnn/partitioned/W", [(0, 64), (0, -1)]) in table
+    # ordered code, longer forms (ordered_code.cc): one byte for [-64, 64), then 7n - 1 magnitude bits in n bytes
+    assert [W._oc_signed(v).hex() for v in (0, -1, 63, -64, 64, -65, 8191, 8192)] == \
+        ["80", "7f", "bf", "40", "c040", "3fbf", "dfff", "e02000"]

@@ -82,3 +82,20 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)
+
+
+def test_bench_strong_scaling_eight_ranks_with_a_ragged_video():
+    """World 8 over gloo on the one test GPU: 13 frame pairs in chunks of 2 = 7 chunks over 8 ranks -- one rank
+    owns no chunk and only takes part in the gathers, the last chunk is ragged.  The line counts the 13 frames once."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"PREMVOS_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch",
+                        "2", "--frames", "13", "--no-cpu-baseline", "--no-roofline", "--file-to-file", "0"], capture_output=True, text=True,
+                       env=env, timeout=2400)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["frames_per_step"] == 13
+    assert abs(d["value"] - 13 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert d["conv_configurations"]["signatures_explored_by_time"] == 0

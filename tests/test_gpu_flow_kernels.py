@@ -398,7 +398,10 @@ def test_pointwise_conv_interior_fast_path_boundaries(seed):
 
 @pytest.mark.parametrize("cin,cout,n,h,w,res,act", [(64, 128, 2, 37, 41, False, "relu"), (64, 256, 1, 50, 50, True, "relu"),
                                                     (128, 128, 3, 19, 23, True, "none"), (128, 512, 1, 31, 17, True, "relu"),
-                                                    (128, 256, 1, 5, 7, False, "leaky"), (64, 128, 1, 300, 301, True, "relu")])
+                                                    (128, 256, 1, 5, 7, False, "leaky"), (64, 128, 1, 300, 301, True, "relu"),
+                                                    # cout = 384: three column tiles do not divide 256 CUs (85 x 3 workgroups
+                                                    # left rows of the third tile unwritten); many steps, and fewer steps than walkers
+                                                    (64, 384, 1, 173, 174, True, "relu"), (128, 384, 1, 10, 10, False, "none")])
 def test_streaming_pointwise_kernel_is_bit_identical_to_the_implicit_gemm(cin, cout, n, h, w, res, act):
     """tile_hint 5 (csrc/conv_stream_f32.hip: persistent workgroups, weights resident in LDS, no workgroup barrier in the loop) adds
     the products of an output in the implicit GEMM's order: the same bits, whatever M (ragged last step, fewer steps than

@@ -68,8 +68,11 @@ def test_proposal_net_full_depth_davis_shape():
     for x, y in zip(js, ref):
         assert abs(x["score"] - y["score"]) <= 0.011 and np.abs(np.array(x["bbox"]) - np.array(y["bbox"])).max() <= 0.11
     # and the whole CPU net agrees with the GPU net where floats are compared with a tolerance
-    common = np.intersect1d(p.roi_idx[0, :n].cpu().numpy(), inter["proposal_idx"])
-    assert len(common) >= 98, len(common)                  # near-ties may swap one or two of the 100 between the two nets (measured: 100 shared, tests/test_gpu_error_budget.py)
+    # (asserted as measured, VERDICT r03 next #1c: all 100 indices are shared with the CPU net; two near-ties of the CPU net itself
+    #  sit at swapped ranks -- tests/test_gpu_error_budget.py records `rpn_indices_same_position` = 98)
+    idx = p.roi_idx[0, :n].cpu().numpy()
+    assert len(np.intersect1d(idx, inter["proposal_idx"])) == 100
+    assert int(np.sum(idx == inter["proposal_idx"][:n])) >= 98
 
 
 def test_proposal_net_full_depth_configs4_shape():

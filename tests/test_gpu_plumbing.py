@@ -397,3 +397,33 @@ def test_acceptance_command_runs_end_to_end_on_a_synthetic_tree(tmp_path):
     r = json.loads((root / "output" / "premvos_amd_davis_eval.json").read_text())
     assert r["mean_J"] == 1.0 and r["mean_F"] == 1.0 and r["sequences"] == 1
     assert json.loads((root / "output" / "premvos_amd_manifest.json").read_text())["frames"] == 4
+
+
+def test_eight_ranks_write_the_one_rank_tree_both_sharding_branches(tmp_path):
+    """World 8 = one MI355X node, the ranks sharing the test box's one GPU over gloo: (a) a ragged
+    3-video tree (5 / 3 / 2 frames, chunks of 2) -- fewer videos than ranks, so every video is cut into chunk-aligned frame ranges,
+    most ranks own one chunk, some own none, the boundary frames are read twice; (b) the same with --gather (ranks without a
+    shard item still take part in every flush); (c) a 9-video tree -- at least as many videos as ranks: whole videos, one rank
+    gets two.  Every tree is byte-identical to the 1-rank run's."""
+    trees = {"ragged": {"bear": 5, "camel": 3, "dog": 2}, "many": {f"v{i}": 1 + (i % 2) for i in range(9)}}
+    for name, videos in trees.items():
+        n_frames = sum(videos.values())
+        n_files = sum(v - 1 for v in videos.values()) + 4 * n_frames
+        roots = []
+        for tag, gpus, extra in [("one", 1, ()), ("eight", 8, ())] + ([("gathered", 8, ("--gather",))] if name == "ragged" else []):
+            root = tmp_path / f"{name}_{tag}"
+            root.mkdir()
+            _make_tree(root, videos=videos)
+            out = _stream_subprocess(root, "--batch", "2", *extra, gpus=gpus)
+            assert f"frames: {n_frames}" in out
+            roots.append(root / "output")
+        for other in roots[1:]:
+            _same_tree(roots[0] / "intermediate", other / "intermediate", n_files)
+        m = json.load(open(roots[1] / "premvos_amd_manifest.json"))
+        assert m["ranks"] == 8 and m["frames"] == n_frames and len(m["shards"]) == 8
+        if name == "ragged":
+            assert sum(1 for p in m["shards"] if not p) >= 1            # 3 + 2 + 1 = 6 chunks... some rank owns nothing
+            assert sorted((v.rstrip("/").split("/")[-1], a, b) for p in m["shards"] for v, a, b in p) == \
+                [("bear", 0, 2), ("bear", 2, 4), ("bear", 4, 5), ("camel", 0, 2), ("camel", 2, 3), ("dog", 0, 2)]
+        else:
+            assert sorted(len(p) for p in m["shards"]) == [1] * 7 + [2]
