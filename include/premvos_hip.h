@@ -41,6 +41,10 @@ extern "C" {
  * store every group of four output channels as the 16 bytes {hi(4 x bf16), lo(4 x bf16)}, x = hi + lo (hi = bf16(x)
  * round-to-nearest-even, lo = bf16(x - hi)), in place of the four floats -- the input form of premvos_pwconv_bf16x3_split_f32 */
 #define PREMVOS_ACT_SPLIT_BF16 0x100
+/* Round 4, same producers: store the result in the resident split layout "S8" instead -- every group of EIGHT channels of a pixel
+ * is the 32 bytes {hi(8 x bf16), lo(8 x bf16)} (pixel stride a multiple of 8 floats' worth, channel window 32-byte aligned) -- the
+ * operand form of premvos_conv_bf16x3_s8_f32. */
+#define PREMVOS_ACT_SPLIT8_BF16 0x200
 
 /* arithmetic of the dense-conv MFMA pipe (activations and outputs are fp32 in HBM in every mode) */
 #define PREMVOS_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products (the parity / default bench mode)        */
@@ -267,6 +271,24 @@ int premvos_pwconv_bf16x3_split_f32(const void* in_split, int32_t in_ps, int64_t
                                     const void* wgt_lo, int32_t k_pad, int32_t cout, int32_t cout_pad, const float* bias,
                                     const float* res, int32_t res_ps, float* out, int32_t out_ps, void* out_split,
                                     int32_t out_split_ps, int32_t act, float slope, void* stream);
+
+/* Round 4: the bf16x3 mode on activations RESIDENT in the split layout "S8" -- per pixel, every group of 8 channels is the 32 bytes
+ * {hi(8 x bf16), lo(8 x bf16)} (x = hi + lo; 4 bytes per element like fp32, pixel stride a multiple of 8 floats' worth of bytes,
+ * channel windows 32-byte aligned).  Any conv of the three nets (1x1 / k x k, stride, dilation, asymmetric zero padding: the same
+ * geometry fields of premvos_conv_desc as premvos_conv2d_f32, out_mode NHWC; replaces what the reference reaches through
+ * tensorpack Conv2D basemodel.py:29-99, slim.conv2d / separable_conv2d's pointwise half xception.py:154-178, nn.Conv2d
+ * PWCNet.py:24-34) as an implicit GEMM on v_mfma_f32_32x32x16_bf16: hi.hi + hi.lo + lo.hi, fp32 accumulate, operands staged by
+ * LDS-DMA.  d->inp / d->wgt are IGNORED: in_s8 = the S8 input (d->in_ps its pixel stride, d->cin % 8 == 0), wgt_s8 = weights
+ * packed as bf16 [cout_pad][kh*kw][ceil(cin/32)][4 groups][hi 8 | lo 8], zero padded (premvos_amd.ops.pack_conv_s8).
+ * Outputs, each optional (at least one): d->out (fp32 NHWC, d->out_ps) and out_s8 (S8, pixel stride out_s8_ps floats' worth) =
+ * act(sum + d->bias (+ d->res, fp32)); cout % 8 == 0.  tile: 0 = 256x256 / 8 waves / 2 buffers, 1 = 256x128 / 4 waves / 3 buffers,
+ * 2 = 256x128 / 4 waves / 2 buffers, 3 = 256x128 / 8 waves / 3 buffers, 4 = 128x128 / 4 waves / 3 buffers, 5 = 128x128 / 2 buffers. */
+int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* d, const void* in_s8, const void* wgt_s8, void* out_s8,
+                               int32_t out_s8_ps, int32_t tile, void* stream);
+
+/* fp32 NHWC [pixels][in_ps] -> S8 [pixels][out_ps floats' worth] (c channels; a partial last group is zero filled): the entry of an
+ * S8 chain whose producer is an fp32 kernel. */
+int premvos_split8_f32(const float* in, int32_t in_ps, void* out_s8, int32_t out_ps, int64_t pixels, int32_t c, void* stream);
 
 /* tf.image.resize_bilinear, TF1: align_corners=1 (model.py:399-400,570-571) or 0 = legacy src = dst*in/out. */
 int premvos_resize_bilinear_f32(const float* in, int32_t in_ps, int32_t n, int32_t h, int32_t w, int32_t c, float* out,

@@ -67,6 +67,38 @@ __device__ __forceinline__ float4 split_bf16_group(const float4 r) {
   return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
 }
 
+// The resident split layout "S8" (round 4, csrc/conv_bf16x3_s8.hip): every group of EIGHT channels of a pixel is the 32 bytes
+// {hi(8 x bf16), lo(8 x bf16)} -- a 16-byte half is exactly one operand of v_mfma_f32_32x32x16_bf16, so the consumer stages it by
+// LDS-DMA and reads fragments with one ds_read_b128, no re-pairing.  x = hi + lo, hi = bf16(x) (round to nearest even), lo = bf16(x - hi).
+__device__ __forceinline__ uint2 bf16_hi4(const float4 r, float4& rest) {
+  using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+  const bf16x4 hi = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
+  rest = make_float4(r.x - (float)hi[0], r.y - (float)hi[1], r.z - (float)hi[2], r.w - (float)hi[3]);
+  return __builtin_bit_cast(uint2, hi);
+}
+__device__ __forceinline__ uint2 bf16_rn4(const float4 r) {
+  using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+  const bf16x4 b = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
+  return __builtin_bit_cast(uint2, b);
+}
+// eight channels (one whole group) -> its 32 bytes at `dst` (32-byte aligned): two 16-byte stores
+__device__ __forceinline__ void store_split8(char* dst, const float4 v0, const float4 v1) {
+  float4 l0, l1;
+  const uint2 h0 = bf16_hi4(v0, l0), h1 = bf16_hi4(v1, l1);
+  const uint2 q0 = bf16_rn4(l0), q1 = bf16_rn4(l1);
+  *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4*>(dst + 16) = make_uint4(q0.x, q0.y, q1.x, q1.y);
+}
+// four channels = HALF a group (producers whose threads own four channels: depthwise convs, Winograd output transforms):
+// `pixel` = the pixel's first byte (channel 0 of the window), cg = index of the 4-channel unit; two 8-byte stores
+__device__ __forceinline__ void store_split4(char* pixel, const int cg, const float4 v) {
+  float4 l;
+  const uint2 h = bf16_hi4(v, l);
+  char* g = pixel + (cg >> 1) * 32 + (cg & 1) * 8;
+  *reinterpret_cast<uint2*>(g) = h;
+  *reinterpret_cast<uint2*>(g + 16) = bf16_rn4(l);
+}
+
 }  // namespace premvos
 
 #define PV_REQUIRE(cond, ...) \

@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const uint8_t* __rest
 
 // PREMVOS_ACT_SPLIT_BF16 (bit 8 of `act`): the depthwise result of four channels is stored split (common.h: split_bf16_group)
 __device__ __forceinline__ float4 split_or_plain(const float4 r, const bool split) { return split ? premvos::split_bf16_group(r) : r; }
+// The store of one (pixel, 4-channel unit) result: floats, the {hi4, lo4} group of round 3, or -- PREMVOS_ACT_SPLIT8_BF16 (bit 9) -- half
+// of a group of the resident S8 layout (common.h: store_split4; csrc/conv_bf16x3_s8.hip reads it by LDS-DMA)
+__device__ __forceinline__ void store_unit(float* pixel, const int cg, const float4 r, const int act) {
+  if (act & PREMVOS_ACT_SPLIT8_BF16) premvos::store_split4(reinterpret_cast<char*>(pixel), cg, r);
+  else *reinterpret_cast<float4*>(pixel + cg * 4) = split_or_plain(r, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
+}
 
 // ------------------------------------------------------------------------------------------
 // Depthwise 3x3 conv (+stride, +atrous) with folded BatchNorm: out = act(sum_taps w*relu?(in) + bias).
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
     if ((act & 0xff) == PREMVOS_ACT_RELU) {
       acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     }
-    *reinterpret_cast<float4*>(out + pix * out_ps + cg * 4) = split_or_plain(acc, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
+    store_unit(out + pix * out_ps, cg, acc, act);
   }
 }
 
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_row_kernel(const float* __restr
       if ((act & 0xff) == PREMVOS_ACT_RELU) {
         r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
       }
-      *reinterpret_cast<float4*>(out + (((long)b * ho + oy) * wo + ox) * out_ps + cg * 4) = split_or_plain(r, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
+      store_unit(out + (((long)b * ho + oy) * wo + ox) * out_ps, cg, r, act);
     }
   }
 }
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
             acc[o][q].x += a.x * kk.x; acc[o][q].y += a.y * kk.y; acc[o][q].z += a.z * kk.z; acc[o][q].w += a.w * kk.w;
           }
         if (kj == 2 && oy0 + o * dil < ho) {       // this output row is complete
-          float* orow = out + (((long)b * ho + oy0 + o * dil) * wo) * out_ps + cg * 4;
+          float* orow = out + (((long)b * ho + oy0 + o * dil) * wo) * out_ps;
 #pragma unroll
           for (int q = 0; q < TW; ++q) {
             if (ox0 + q * dil >= wo) break;
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_tile_kernel(const float* __rest
             if ((act & 0xff) == PREMVOS_ACT_RELU) {
               r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
             }
-            *reinterpret_cast<float4*>(orow + (long)(ox0 + q * dil) * out_ps) = split_or_plain(r, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
+            store_unit(orow + (long)(ox0 + q * dil) * out_ps, cg, r, act);
           }
         }
       }
@@ -469,8 +475,12 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
   PV_REQUIRE(premvos::aligned16(in) && premvos::aligned16(out) && premvos::aligned16(wgt) &&
                  (bias == nullptr || premvos::aligned16(bias)),
              "dwconv3x3: pointers must be 16-byte aligned");
-  PV_REQUIRE((act & ~PREMVOS_ACT_SPLIT_BF16) == PREMVOS_ACT_NONE || (act & ~PREMVOS_ACT_SPLIT_BF16) == PREMVOS_ACT_RELU,
-             "dwconv3x3: bad activation");
+  PV_REQUIRE((act & 0xff) == PREMVOS_ACT_NONE || (act & 0xff) == PREMVOS_ACT_RELU, "dwconv3x3: bad activation");
+  PV_REQUIRE((act & ~0xff & ~PREMVOS_ACT_SPLIT_BF16 & ~PREMVOS_ACT_SPLIT8_BF16) == 0 &&
+                 (act & (PREMVOS_ACT_SPLIT_BF16 | PREMVOS_ACT_SPLIT8_BF16)) != (PREMVOS_ACT_SPLIT_BF16 | PREMVOS_ACT_SPLIT8_BF16),
+             "dwconv3x3: unknown output-layout flags");
+  PV_REQUIRE(!(act & PREMVOS_ACT_SPLIT8_BF16) || (out_ps % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31u) == 0),
+             "dwconv3x3: an S8 output needs out_ps %% 8 == 0 and a 32-byte aligned channel window");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (stride == 1 && (wo + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3) &&
       (ho + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3)) {   // register-tiled fast path (stride 2: row kernel wins)

@@ -23,11 +23,14 @@ def _r(x: int, m: int) -> int:
 class NHWC:
     """A channel window [coff, coff+c) of a pixel-major fp32 buffer [n,h,w,ps]."""
 
-    __slots__ = ("buf", "n", "h", "w", "c", "ps", "coff")
+    __slots__ = ("buf", "n", "h", "w", "c", "ps", "coff", "layout")
 
-    def __init__(self, buf: torch.Tensor, c: Optional[int] = None, coff: int = 0):
+    def __init__(self, buf: torch.Tensor, c: Optional[int] = None, coff: int = 0, layout: str = "f32"):
         assert buf.dim() == 4 and buf.dtype == torch.float32 and buf.is_contiguous()
         self.buf = buf
+        # "f32": floats.  "s8": the resident split layout of the bf16x3 mode (csrc/conv_bf16x3_s8.hip) -- every group of 8 channels is
+        # the 32 bytes {hi(8 x bf16), lo(8 x bf16)} stored IN PLACE of its eight floats; readers that expect floats refuse such a buffer
+        self.layout = layout
         self.n, self.h, self.w, self.ps = buf.shape
         self.coff = coff
         self.c = self.ps - coff if c is None else c
@@ -39,17 +42,27 @@ class NHWC:
         return NHWC(torch.zeros((n, h, w, ps), dtype=torch.float32, device=device), c=c)
 
     def slice(self, coff: int, c: int) -> "NHWC":
-        return NHWC(self.buf, c=c, coff=self.coff + coff)
+        assert self.layout == "f32" or (coff % 8 == 0 and c % 8 == 0), "an S8 window starts and ends on a group of 8 channels"
+        return NHWC(self.buf, c=c, coff=self.coff + coff, layout=self.layout)
 
     def images(self, n0: int, n: int) -> "NHWC":
-        return NHWC(self.buf[n0:n0 + n], c=self.c, coff=self.coff)
+        return NHWC(self.buf[n0:n0 + n], c=self.c, coff=self.coff, layout=self.layout)
+
+    @staticmethod
+    def alloc_s8(n: int, h: int, w: int, c: int, device="cuda") -> "NHWC":
+        v = NHWC(torch.zeros((n, h, w, _r(c, 8)), dtype=torch.float32, device=device), c=c, layout="s8")
+        return v
 
     @property
     def ptr(self) -> int:
         return self.buf.data_ptr() + 4 * self.coff
 
     def torch(self) -> torch.Tensor:
-        """NCHW copy (tests / debugging)."""
+        """NCHW copy (tests / debugging); an S8 buffer is decoded (hi + lo, the value its consumers multiply)."""
+        if self.layout == "s8":
+            g = self.buf[..., self.coff:self.coff + _r(self.c, 8)].contiguous().view(torch.bfloat16)      # [n,h,w,groups*16]
+            g = g.view(self.n, self.h, self.w, -1, 2, 8).float()
+            return (g[..., 0, :] + g[..., 1, :]).reshape(self.n, self.h, self.w, -1)[..., :self.c].permute(0, 3, 1, 2).contiguous()
         return self.buf[..., self.coff:self.coff + self.c].permute(0, 3, 1, 2).contiguous()
 
 
@@ -207,6 +220,7 @@ def conv_desc(x: NHWC, pk: PackedConv, out: NHWC, stride=(1, 1), dilation=(1, 1)
     """Build the descriptor (validated again on the C side).  ``pad`` = (top, left); the output
     size comes from ``out`` so asymmetric bottom/right padding is implicit."""
     assert x.c == pk.cin, (x.c, pk.cin)
+    assert x.layout == "f32" and out.layout == "f32" and (res is None or res.layout == "f32"), "fp32 kernels read and write floats (S8 buffers: conv_s8)"
     d = ConvDesc()
     d.inp, d.wgt = x.ptr, pk.wgt.data_ptr()
     d.bias = pk.bias.data_ptr() if pk.bias is not None else None
@@ -635,6 +649,101 @@ def autotune(descs, device="cuda", reps: int = 4):
                 save_tune_cache(cache_file)
         for d in descs:
             d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = _entry_for(d)
+
+
+@dataclass
+class PackedConvS8:
+    """Weights of one conv for csrc/conv_bf16x3_s8.hip: bf16 [cout_pad][kh*kw][ceil(cin/32)][4 groups][hi 8 | lo 8]."""
+    wgt: torch.Tensor
+    bias: Optional[torch.Tensor]
+    cin: int
+    cout: int
+    kh: int
+    kw: int
+    cout_pad: int
+
+
+def pack_conv_s8(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda", scale: Optional[torch.Tensor] = None) -> PackedConvS8:
+    """OIHW fp32 -> the S8 operand layout: row n = output channel, then (tap, block of 32 input channels, group of 8, hi | lo), zero
+    padded; w = hi + lo with hi = bf16(w), lo = bf16(w - hi).  ``scale`` folds a frozen BatchNorm's gamma / sqrt(var + eps) in."""
+    w = weight.detach().to(torch.float32).cpu()
+    cout, cin, kh, kw = w.shape
+    if scale is not None:
+        w = w * scale.detach().to(torch.float32).cpu().view(-1, 1, 1, 1)
+    cout_pad, kc = _r(cout, 32), -(-cin // 32)
+    full = torch.zeros((cout_pad, kh * kw, kc * 32), dtype=torch.float32)
+    full[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    hi = full.to(torch.bfloat16)
+    lo = (full - hi.float()).to(torch.bfloat16)
+    both = torch.stack([hi.view(cout_pad, kh * kw, kc, 4, 8), lo.view(cout_pad, kh * kw, kc, 4, 8)], dim=4)     # [..., group, part, 8]
+    b = None
+    if bias is not None:
+        b = torch.zeros(cout_pad, dtype=torch.float32)
+        b[:cout] = bias.detach().to(torch.float32).cpu()
+        b = b.to(device)
+    return PackedConvS8(both.contiguous().to(device), b, cin, cout, kh, kw, cout_pad)
+
+
+def conv_s8_desc(x: NHWC, pk: PackedConvS8, out: Optional[NHWC], out_s8: Optional[NHWC], stride=(1, 1), dilation=(1, 1), pad=(0, 0),
+                 act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None) -> ConvDesc:
+    """Geometry / epilogue descriptor of one S8 conv launch (premvos_conv_bf16x3_s8_f32); the output size comes from the outputs."""
+    o = out if out is not None else out_s8
+    assert x.layout == "s8" and x.c == pk.cin and x.c % 8 == 0 and x.coff % 8 == 0, (x.layout, x.c, pk.cin, x.coff)
+    assert o is not None and o.c == pk.cout and o.n == x.n and pk.cout % 8 == 0
+    assert out is None or out.layout == "f32"
+    assert out_s8 is None or (out_s8.layout == "s8" and (out_s8.n, out_s8.h, out_s8.w, out_s8.c) == (o.n, o.h, o.w, o.c) and out_s8.coff % 8 == 0)
+    assert res is None or (res.layout == "f32" and (res.n, res.h, res.w, res.c) == (o.n, o.h, o.w, o.c))
+    d = ConvDesc()
+    d.inp, d.wgt = None, None
+    d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    d.res = res.ptr if res is not None else None
+    d.out = out.ptr if out is not None else None
+    d.n, d.h, d.w, d.cin, d.in_ps = x.n, x.h, x.w, x.c, x.ps
+    d.ho, d.wo, d.cout = o.h, o.w, pk.cout
+    d.out_ps = out.ps if out is not None else 0
+    d.res_ps = res.ps if res is not None else 0
+    d.kh, d.kw = pk.kh, pk.kw
+    d.sh, d.sw = stride
+    d.dh, d.dw = dilation
+    d.pt, d.pl = pad
+    d.cin_pad, d.k_pad, d.cout_pad = _r(pk.cin, 32), pk.kh * pk.kw * _r(pk.cin, 32), pk.cout_pad
+    d.act, d.slope, d.out_mode, d.cout_ps = act, slope, OUT_NHWC, 0
+    d.precision = _lib.PREC_BF16X3
+    return d
+
+
+S8_HINT = 6          # ConvDesc.tile_hint of a launch that goes to premvos_conv_bf16x3_s8_f32 (a marker for tables / reports: that entry has one kernel)
+
+
+def s8_tile_rule(m: int, cout: int) -> int:
+    """Tile of an S8 conv as a closed-form function of its shape (no timing: the same kernel on every rank and run): 256 x 256 /
+    eight waves where both dimensions fill it and the launch still has > 1.5 rounds of workgroups, 256 x 128 for narrower layers,
+    128 x 128 for small maps."""
+    if cout > 128 and -(-m // 256) * -(-cout // 256) >= 384:
+        return 0
+    if -(-m // 256) * -(-cout // 128) >= 256:
+        return 1
+    return 4
+
+
+def conv_s8(x: NHWC, pk: PackedConvS8, out: Optional[NHWC] = None, out_s8: Optional[NHWC] = None, tile: Optional[int] = None, **kw):
+    d = conv_s8_desc(x, pk, out, out_s8, **kw)
+    run_s8(d, x, pk, out_s8, tile)
+    return out if out is not None else out_s8
+
+
+def run_s8(d: ConvDesc, x: NHWC, pk: PackedConvS8, out_s8: Optional[NHWC], tile: Optional[int] = None, stream: Optional[int] = None):
+    t = s8_tile_rule(d.n * d.ho * d.wo, d.cout) if tile is None else tile
+    _lib.check(_lib.load().premvos_conv_bf16x3_s8_f32(C.byref(d), x.ptr, pk.wgt.data_ptr(), out_s8.ptr if out_s8 is not None else None,
+                                                      out_s8.ps if out_s8 is not None else 0, t,
+                                                      _lib.current_stream() if stream is None else stream), "conv_bf16x3_s8")
+
+
+def split8(x: NHWC, out: NHWC):
+    """fp32 NHWC -> S8 (same shape): the entry of an S8 chain whose producer is an fp32 kernel."""
+    assert x.layout == "f32" and out.layout == "s8" and (x.n, x.h, x.w, x.c) == (out.n, out.h, out.w, out.c) and out.coff % 8 == 0
+    _lib.check(_lib.load().premvos_split8_f32(x.ptr, x.ps, out.ptr, out.ps, x.n * x.h * x.w, x.c, _lib.current_stream()), "split8")
+    return out
 
 
 def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):

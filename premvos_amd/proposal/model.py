@@ -77,26 +77,36 @@ class _Plan:
             keep.append(v)
             return v
 
-        def conv(x, name, out, uid=None, **kw):
-            pk = P[name]
-            d = ops.conv_desc(x, pk, out, **kw)
-            self.descs.append(d)
+        S8 = net.packed_s8
+        self.tune_descs: List = []     # the launches premvos_conv2d_f32 runs (ops.autotune configures these; S8 convs have one kernel)
+
+        def alloc_s8(n, hh, ww, c):
+            v = NHWC.alloc_s8(n, hh, ww, c, dev)
+            keep.append(v)
+            return v
+
+        def conv(x, name, out, uid=None, out_s8=None, **kw):
+            """``x`` in the resident split layout S8 (bf16x3 mode) -> csrc/conv_bf16x3_s8.hip (fp32 ``out`` and / or S8 ``out_s8``);
+            fp32 ``x`` -> premvos_conv2d_f32."""
             key = "conv:" + (uid or name)
-            # split_in / out_split are decided after the tuner has fixed the kernel families (see `chains` below)
-            rec = {"d": d, "pk": pk, "out": out, "split_in": None, "out_split": None}
+            if x.layout == "s8":
+                pk = S8[name]
+                d = ops.conv_s8_desc(x, pk, out, out_s8, **kw)
+                d.tile_hint = ops.S8_HINT
+                o = out if out is not None else out_s8
+                steps.append((key, lambda d=d, x=x, pk=pk, o8=out_s8: ops.run_s8(d, x, pk, o8)))
+                self.split_layers += 1
+            else:
+                assert out_s8 is None
+                pk = P[name]
+                d = ops.conv_desc(x, pk, out, **kw)
+                self.tune_descs.append(d)
+                o = out
+                steps.append((key, lambda d=d: ops.run_desc(d)))
+            self.descs.append(d)
+            self.flops[key] = 2.0 * o.n * o.h * o.w * pk.kh * pk.kw * pk.cin * pk.cout
 
-            def run(rec=rec, kw=kw):
-                if rec["split_in"] is not None:
-                    ops.pwconv_bf16x3_split(rec["split_in"], rec["pk"], rec["out"], act=kw.get("act", ACT_NONE), res=kw.get("res"),
-                                            out_split=rec["out_split"])
-                else:
-                    ops.run_desc(rec["d"])
-            steps.append((key, run))
-            self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
-            return rec
-
-        chains: List = []       # (conv3 of the block before or None, conv1, conv2, conv3) of every bottleneck, in launch order
-
+        self.split_layers = 0          # convs on the S8 kernel (bf16x3 mode)
         self.img = alloc(b, h, w, 3)
         # conv0: pad [2,3] + 7x7 s2 VALID + BN + ReLU; pool0: pad [0,1] + 3x3 s2 VALID  (basemodel.py:79-82)
         h0, w0 = ops.out_size(h, 7, 2, 2, 3), ops.out_size(w, 7, 2, 2, 3)
@@ -110,41 +120,53 @@ class _Plan:
                                                0.0, _lib.current_stream()), "maxpool")
         steps.append(("maxpool", pool))
 
-        def group(x: NHWC, g: int, feat: int, count: int, stride: int, tag: str = "", before=None) -> NHWC:
+        def group(x: NHWC, g: int, feat: int, count: int, stride: int, tag: str = "", x8: Optional[NHWC] = None,
+                  last_s8: bool = False):
+            """One ResNet group (basemodel.py:62-72).  fp32 mode: every tensor is floats.  bf16x3 mode, groups >= net.s8_from: the
+            bottleneck chain lives in S8 -- conv1 and conv2 write S8 only (one reader each), conv3 = relu(bn(conv3) + shortcut)
+            writes the fp32 block output (the next block's residual, RoIAlign's input) AND its S8 copy (the next conv1's /
+            shortcut conv's / RPN's operand); ``x8``: the S8 copy of ``x`` when the producer already wrote one.  Returns (y, y8)."""
+            s8 = net.s8 and g >= net.s8_from
             for i in range(count):
                 p = f"group{g}/block{i}"
                 s = stride if i == 0 else 1
-                t1 = alloc(x.n, x.h, x.w, feat)
-                r1 = conv(x, p + "/conv1", t1, uid=tag + p + "/conv1", act=ACT_RELU)
+                if s8 and x8 is None:                   # entry of the chain: one split pass over the fp32 tensor
+                    x8 = alloc_s8(x.n, x.h, x.w, x.c)
+                    steps.append((f"split8:{tag}{p}", lambda i_=x, o_=x8: ops.split8(i_, o_)))
+                xin = x8 if s8 else x
+                mk = alloc_s8 if s8 else alloc
+                t1 = mk(x.n, x.h, x.w, feat)
+                o1 = dict(out=None, out_s8=t1) if s8 else dict(out=t1)
+                conv(xin, p + "/conv1", uid=tag + p + "/conv1", act=ACT_RELU, **o1)
                 if s == 2:        # pad [0,1] + VALID stride 2  (basemodel.py:54-56)
                     ho, wo = ops.out_size(x.h, 3, 2, 0, 1), ops.out_size(x.w, 3, 2, 0, 1)
-                    t2 = alloc(x.n, ho, wo, feat)
-                    r2 = conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", stride=(2, 2), pad=(0, 0), act=ACT_RELU)
+                    t2 = mk(x.n, ho, wo, feat)
+                    o2 = dict(out=None, out_s8=t2) if s8 else dict(out=t2)
+                    conv(t1, p + "/conv2", uid=tag + p + "/conv2", stride=(2, 2), pad=(0, 0), act=ACT_RELU, **o2)
                 else:
-                    t2 = alloc(x.n, x.h, x.w, feat)
-                    r2 = conv(t1, p + "/conv2", t2, uid=tag + p + "/conv2", pad=(1, 1), act=ACT_RELU)
-                if p + "/convshortcut" in P:   # 1x1 stride s on x[:, :, :-1, :-1] == reading pixel (s*oy, s*ox)
+                    t2 = mk(x.n, x.h, x.w, feat)
+                    o2 = dict(out=None, out_s8=t2) if s8 else dict(out=t2)
+                    conv(t1, p + "/conv2", uid=tag + p + "/conv2", pad=(1, 1), act=ACT_RELU, **o2)
+                if p + "/convshortcut" in P or p + "/convshortcut" in S8:   # 1x1 stride s on x[:, :, :-1, :-1] == reading pixel (s*oy, s*ox)
                     sc = alloc(x.n, t2.h, t2.w, feat * 4)
-                    conv(x, p + "/convshortcut", sc, uid=tag + p + "/convshortcut", stride=(s, s))
+                    conv(xin, p + "/convshortcut", sc, uid=tag + p + "/convshortcut", stride=(s, s))
                 else:
                     sc = x
                 y = alloc(x.n, t2.h, t2.w, feat * 4)
-                r3 = conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
-                chains.append((before, r1, r2, r3))
-                before = r3
-                x = y
-            self._last3 = before
-            return x
+                y8 = alloc_s8(x.n, t2.h, t2.w, feat * 4) if s8 and (i + 1 < count or last_s8) else None
+                conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", out_s8=y8, res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
+                x, x8 = y, y8
+            return x, x8
 
         nb = net.num_blocks
-        x = group(x, 0, 64, nb[0], 1)
-        x = group(x, 1, 128, nb[1], 2, before=self._last3)
-        fm = group(x, 2, 256, nb[2], 2, before=self._last3)
+        x, x8 = group(x, 0, 64, nb[0], 1, last_s8=net.s8 and net.s8_from <= 0)
+        x, x8 = group(x, 1, 128, nb[1], 2, x8=x8, last_s8=net.s8 and net.s8_from <= 1)
+        fm, fm8 = group(x, 2, 256, nb[2], 2, x8=x8, last_s8=net.s8)
         self.featuremap = fm
         fh, fw = fm.h, fm.w
         # rpn_head (model.py:30-51): 3x3 + ReLU, then class(15) + box(60) as one 1x1 conv
         hid = alloc(b, fh, fw, 1024)
-        conv(fm, "rpn/conv0", hid, pad=(1, 1), act=ACT_RELU)
+        conv(fm8 if fm8 is not None else fm, "rpn/conv0", hid, pad=(1, 1), act=ACT_RELU)
         self.rpn_out = alloc(b, fh, fw, 5 * NUM_ANCHOR)
         conv(hid, "rpn/heads", self.rpn_out)
         R = TEST_POST_NMS_TOPK
@@ -169,7 +191,7 @@ class _Plan:
                                                  self.roi_count.data_ptr(), R, 1.0 / ANCHOR_STRIDE, 14, o.ptr, o.ps,
                                                  _lib.current_stream()), "roi_align")
         steps.append(("roi_align", ralign))
-        f5 = group(roi, 3, 512, nb[3], 2)            # resnet_conv5 (basemodel.py:92-99)
+        f5, _ = group(roi, 3, 512, nb[3], 2)         # resnet_conv5 (basemodel.py:92-99)
         self.feat5 = f5
         gp = alloc(b * R, 1, 1, 2048)
 
@@ -204,33 +226,13 @@ class _Plan:
                                                      self.final_count.data_ptr(), M, 1.0 / ANCHOR_STRIDE, 14, o.ptr,
                                                      o.ps, _lib.current_stream()), "roi_align(mask)")
             steps.append(("roi_align_mask", malign))
-            mf5 = group(mroi, 3, 512, nb[3], 2, tag="mask:")   # the SAME conv5 weights (auto_reuse_variable_scope)
+            mf5, _ = group(mroi, 3, 512, nb[3], 2, tag="mask:")   # the SAME conv5 weights (auto_reuse_variable_scope)
             up = alloc(b * M, 14, 14, 256)
             conv(mf5, "maskrcnn/deconv", up, act=ACT_RELU)
             self.final_masks = alloc(b * M, 14, 14, NUM_CLASS - 1)
             conv(up, "maskrcnn/conv", self.final_masks, act=ACT_SIGMOID)
         self.steps, self.buffers = steps, keep
-        self.ws_splitk = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)
-        # bf16x3 mode, after the kernel families are fixed: a 3x3 layer that runs as F(4x4,3x3) stores its output as {hi, lo}
-        # bf16 groups (in place of the floats; its only reader is conv3) and conv3 runs on the kernel that stages pure bf16
-        # (csrc/pwconv_bf16x3_split.hip: 2x the rate of splitting fp32 activations in every column tile); that conv3 writes its
-        # output twice -- fp32 for the residual add / shortcut / RPN / RoIAlign, and split for the next block's conv1
-        self.split_layers = 0
-        if net.split_1x1:
-            ys_pool: Dict[tuple, NHWC] = {}      # one split copy per shape: it lives from a conv3 to the next block's conv1
-            for before, r1, r2, r3 in chains:
-                if before is not None and before["split_in"] is not None and r1["pk"].precision == _lib.PREC_BF16X3:
-                    o = before["out"]
-                    shape = (o.n, o.h, o.w, o.c)
-                    if shape not in ys_pool:
-                        ys_pool[shape] = alloc(*shape)
-                    before["out_split"] = r1["split_in"] = ys_pool[shape]
-                    self.split_layers += 1
-                if r2["d"].tile_hint == 4 and r2["d"].precision == _lib.PREC_F32 and r3["pk"].precision == _lib.PREC_BF16X3 \
-                        and r2["out"].ps % 4 == 0:
-                    r2["d"].act |= _lib.ACT_SPLIT_BF16
-                    r3["split_in"] = r2["out"]
-                    self.split_layers += 1
+        self.ws_splitk = ops.assign_workspace(ops.autotune(self.tune_descs, dev) or self.tune_descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def run(self, steps=None):
@@ -267,19 +269,23 @@ class ProposalNet:
         self._plans: Dict[tuple, _Plan] = {}
         self.cell_anchors_dev = torch.from_numpy(cell_anchors()).to(device)
         w = weights
-        # bf16x3 (split-fp32) mode: the 3x3 layers stay on the fp32 kernels -- Winograd F(4x4,3x3) spends 4x fewer multiplies
-        # (2x the rate of three bf16 MFMAs per product on these shapes) -- and only the 1x1 layers (47 % of the backbone's
-        # multiplies) run as hi.hi + hi.lo + lo.hi.  PREMVOS_BF16X3_HYBRID=0: every layer on the bf16 pipe, as in round 1.
+        # bf16x3 (split-fp32) mode, round 4: from group ``s8_from`` on (PREMVOS_BF16X3_S8_FROM, default 1: group0's K = 64 layers are
+        # HBM-bound on any pipe) every conv of the bottleneck chains, the RPN 3x3 and conv5 runs on csrc/conv_bf16x3_s8.hip with its
+        # input resident in the split layout S8; the rest (conv0, group0, the 75- / 87-channel heads) on the on-the-fly bf16x3 kernel
         import os
-        hybrid = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_HYBRID", "1") != "0"
-        # PREMVOS_BF16X3_SPLIT=0: no {hi, lo} activation layout anywhere; PREMVOS_BF16X3_SPLIT_PROP=0: not in this net (A/B: tools/dev/hyb.sh)
-        self.split_1x1 = hybrid and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" \
-            and os.environ.get("PREMVOS_BF16X3_SPLIT_PROP", "1") != "0"
+        self.s8 = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0"
+        self.s8_from = int(os.environ.get("PREMVOS_BF16X3_S8_FROM", "1"))
+        self.packed_s8: Dict[str, ops.PackedConvS8] = {}
         for name in [k[:-2] for k in w if k.endswith("/W") and (k[:-2] + "/bn") in w]:
             scale, bias = _fold_bn(w[name + "/bn"])
-            lp = "fp32" if hybrid and tuple(w[name + "/W"].shape[2:]) == (3, 3) else prec
-            self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale, precision=lp)
-        self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device, precision="fp32" if hybrid else prec)
+            if self.s8 and name.startswith("group") and int(name[5]) >= self.s8_from:
+                self.packed_s8[name] = ops.pack_conv_s8(w[name + "/W"], bias, device, scale=scale)
+            else:       # (with S8 chains: conv0 / the HBM-bound group-0 layers stay on the fp32 kernels the shipped table tunes)
+                self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale, precision="fp32" if self.s8 else prec)
+        if self.s8:
+            self.packed_s8["rpn/conv0"] = ops.pack_conv_s8(w["rpn/conv0/W"], w["rpn/conv0/b"], device)
+        else:
+            self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device, precision=prec)
         self.packed["rpn/heads"] = ops.pack_conv(torch.cat([w["rpn/class/W"], w["rpn/box/W"]], 0),
                                                  torch.cat([w["rpn/class/b"], w["rpn/box/b"]], 0), device, precision=prec)
         hw = torch.cat([w["fastrcnn/class/W"], w["fastrcnn/box/W"], w["secondclassification/class/W"]], 0)

@@ -103,29 +103,48 @@ class _Plan:
         def release(v: NHWC):
             pool.setdefault((v.n, v.h, v.w, v.c), []).append(v)
 
-        # bf16x3 mode: the depthwise half of a separable conv stores its result already split into bf16 hi / lo (in place of the
-        # floats) and the pointwise half runs on the kernel that stages pure bf16 (csrc/pwconv_bf16x3_split.hip)
+        # bf16x3 mode (round 4): the depthwise half of a separable conv stores its result in the resident split layout S8 (in place of
+        # the floats: {hi8, lo8} per group of 8 channels) and the pointwise half runs on csrc/conv_bf16x3_s8.hip, which stages it by
+        # LDS-DMA; ASPP's concat buffer is S8 as well (its only reader is concat_projection)
         split_pw = net.precision == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0"
         self.split_pw = split_pw
+        S8 = net.packed_s8
+        self.tune_descs: List = []     # the launches premvos_conv2d_f32 runs (ops.autotune configures these; S8 convs have one kernel)
 
-        def conv(x, name, out, split_in=False, **kw):
-            pk = PK[name]
-            d = ops.conv_desc(x, pk, out, **kw)
-            self.descs.append(d)
+        def alloc_s8(n, h, w, c) -> NHWC:
+            key = (n, h, w, c, "s8")
+            if pool.get(key):
+                return pool[key].pop()
+            v = NHWC.alloc_s8(n, h, w, c, dev)
+            keep.append(v)
+            return v
+
+        def release(v: NHWC):                                   # (redefined: S8 buffers live in their own pool)
+            pool.setdefault((v.n, v.h, v.w, v.c) + (("s8",) if v.layout == "s8" else ()), []).append(v)
+
+        def conv(x, name, out, out_s8=None, **kw):
+            """``x`` in S8 -> the S8 kernel (fp32 ``out`` and / or S8 ``out_s8``); fp32 ``x`` -> premvos_conv2d_f32."""
             key = f"conv:{name}"
-            if split_in:
-                assert (pk.kh, pk.kw) == (1, 1) and not kw.get("stride") and not kw.get("pad")
-                steps.append((key, lambda x=x, pk=pk, out=out, kw=kw: ops.pwconv_bf16x3_split(
-                    x, pk, out, act=kw.get("act", ACT_NONE), slope=kw.get("slope", 0.1), res=kw.get("res"))))
+            if x.layout == "s8":
+                pk = S8[name]
+                d = ops.conv_s8_desc(x, pk, out, out_s8, **kw)
+                d.tile_hint = ops.S8_HINT
+                o = out if out is not None else out_s8
+                steps.append((key, lambda d=d, x=x, pk=pk, o8=out_s8: ops.run_s8(d, x, pk, o8)))
             else:
+                assert out_s8 is None
+                pk = PK[name]
+                d = ops.conv_desc(x, pk, out, **kw)
+                self.tune_descs.append(d)
+                o = out
                 steps.append((key, lambda d=d: ops.run_desc(d)))
-            self.flops[key] = 2.0 * out.n * out.h * out.w * pk.kh * pk.kw * pk.cin * pk.cout
+            self.descs.append(d)
+            self.flops[key] = 2.0 * o.n * o.h * o.w * pk.kh * pk.kw * pk.cin * pk.cout
 
         def dwconv(x: NHWC, name: str, out: NHWC, stride=1, rate=1, pre_relu=False, act=ACT_NONE):
             k = DW[name]
-            assert x.c == k.c and out.c == k.c
-
-            flags = act | (_lib.ACT_SPLIT_BF16 if split_pw else 0)     # (every depthwise conv of this net feeds one pointwise conv)
+            assert x.c == k.c and out.c == k.c and x.layout == "f32"
+            flags = act | (_lib.ACT_SPLIT8_BF16 if out.layout == "s8" else 0)
 
             def f(x=x, out=out, k=k):
                 _lib.check(lib.premvos_dwconv3x3_f32(x.ptr, x.ps, x.n, x.h, x.w, x.c, k.wgt.data_ptr(),
@@ -134,6 +153,8 @@ class _Plan:
                            "dwconv3x3")
             steps.append((f"dw:{name}", f))
             self.dw_bytes[f"dw:{name}"] = 4.0 * k.c * (x.n * x.h * x.w + out.n * out.h * out.w)
+
+        alloc_mid = alloc_s8 if split_pw else alloc             # the tensor between the two halves of a separable conv
 
         S = INPUT_SIZE
         self.frames = torch.zeros((G, H, W, 3), dtype=torch.uint8, device=dev)
@@ -178,7 +199,7 @@ class _Plan:
             for i, d in enumerate(depths):
                 s = stride if i == 2 else 1
                 ho = ops.out_size(cur.h, 3, s, rate, rate, rate)
-                t = alloc(P, ho, ho, cur.c)
+                t = alloc_mid(P, ho, ho, cur.c)
                 dwconv(cur, f"{prefix}/separable_conv{i + 1}_depthwise", t, stride=s, rate=rate, pre_relu=not relu_in,
                        act=act)
                 o = alloc(P, ho, ho, d)
@@ -187,7 +208,7 @@ class _Plan:
                     res = sc
                 elif i == 2 and skip == "sum":
                     res = inp
-                conv(t, f"{prefix}/separable_conv{i + 1}_pointwise", o, split_in=split_pw, act=act, res=res)
+                conv(t, f"{prefix}/separable_conv{i + 1}_pointwise", o, act=act, res=res)
                 release(t)
                 if cur is not inp:
                     if f"{prefix}/separable_conv{i}" == DECODER_SKIP:
@@ -204,19 +225,30 @@ class _Plan:
         fh = feat.h
 
         # ASPP (model.py:383-433): [image pooling | 1x1 | 3 atrous separable] -> concat 1280 -> 1x1 256
-        cat = alloc(P, fh, fh, 1280)
+        cat = alloc_mid(P, fh, fh, 1280)
+        cat8 = cat.layout == "s8"
         gp = alloc(P, 1, 1, 2048)
         steps.append(("gap", lambda i=feat, o=gp: _lib.check(lib.premvos_global_avgpool_f32(
             i.ptr, i.ps, i.n, i.h * i.w, i.c, o.ptr, o.ps, _lib.current_stream()), "gap")))
         ip = alloc(P, 1, 1, 256)
         conv(gp, "image_pooling", ip, act=ACT_RELU)
-        steps.append(("broadcast", lambda i=ip, o=cat.slice(0, 256): _lib.check(lib.premvos_broadcast_pixel_f32(
+        bc = alloc(P, fh, fh, 256) if cat8 else cat.slice(0, 256)
+        steps.append(("broadcast", lambda i=ip, o=bc: _lib.check(lib.premvos_broadcast_pixel_f32(
             i.ptr, i.ps, i.n, 256, o.ptr, o.ps, o.h, o.w, _lib.current_stream()), "broadcast")))
-        conv(feat, "aspp0", cat.slice(256, 256), act=ACT_RELU)
+        if cat8:       # the S8 concat buffer: the broadcast and the (fp32-input) 1x1 branch go through an fp32 block and are split once
+            steps.append(("split8:image_pooling", lambda i=bc, o=cat.slice(0, 256): ops.split8(i, o)))
+            a0 = alloc(P, fh, fh, 256)
+            conv(feat, "aspp0", a0, act=ACT_RELU)
+            steps.append(("split8:aspp0", lambda i=a0, o=cat.slice(256, 256): ops.split8(i, o)))
+        else:
+            conv(feat, "aspp0", cat.slice(256, 256), act=ACT_RELU)
         for i, r in enumerate(ATROUS_RATES, 1):
-            t = alloc(P, fh, fh, 2048)
+            t = alloc_mid(P, fh, fh, 2048)
             dwconv(feat, f"aspp{i}_depthwise", t, rate=r, act=ACT_RELU)
-            conv(t, f"aspp{i}_pointwise", cat.slice(256 * (i + 1), 256), split_in=split_pw, act=ACT_RELU)
+            if cat8:
+                conv(t, f"aspp{i}_pointwise", None, cat.slice(256 * (i + 1), 256), act=ACT_RELU)
+            else:
+                conv(t, f"aspp{i}_pointwise", cat.slice(256 * (i + 1), 256), act=ACT_RELU)
             release(t)
         aspp = alloc(P, fh, fh, 256)
         conv(cat, "concat_projection", aspp, act=ACT_RELU)
@@ -231,10 +263,10 @@ class _Plan:
         conv(skip_feat, "decoder/feature_projection0", dcat.slice(256, 48), act=ACT_RELU)
         d = dcat
         for j in (0, 1):
-            t = alloc(P, dh, dh, d.c)
+            t = alloc_mid(P, dh, dh, d.c)
             dwconv(d, f"decoder/decoder_conv{j}_depthwise", t, act=ACT_RELU)
             o = alloc(P, dh, dh, 256)
-            conv(t, f"decoder/decoder_conv{j}_pointwise", o, split_in=split_pw, act=ACT_RELU)
+            conv(t, f"decoder/decoder_conv{j}_pointwise", o, act=ACT_RELU)
             d = o
         self.decoder_out = d
         self.logits = alloc(P, dh, dh, 2)
@@ -266,7 +298,7 @@ class _Plan:
                     self.conf_g[g].data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
         steps.append(("refine_output", out_layer))
         self.steps, self.buffers = steps, keep
-        self.ws_splitk = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)
+        self.ws_splitk = ops.assign_workspace(ops.autotune(self.tune_descs, dev) or self.tune_descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
     def run(self, steps=None):
@@ -298,6 +330,7 @@ class RefinementNet:
         self.precision = prec = precision or ops.default_precision()
         self.device, self.use_graph, self.num_middle = device, use_graph, num_middle
         self.packed: Dict[str, ops.PackedConv] = {}
+        self.packed_s8: Dict[str, ops.PackedConvS8] = {}     # bf16x3 mode: the convs whose input is resident in the S8 layout
         self.packed_dw: Dict[str, PackedDW] = {}
         self._plans: Dict[tuple, _Plan] = {}
         self._plans_lock = __import__("threading").Lock()
@@ -311,6 +344,11 @@ class RefinementNet:
             elif k.endswith("/weights"):
                 if scope + "/BatchNorm" in weights:
                     scale, bias = _fold(weights[scope + "/BatchNorm"], eps)
+                    s8 = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" and \
+                        (scope.endswith("_pointwise") or scope == "concat_projection")
+                    if s8:
+                        self.packed_s8[scope] = ops.pack_conv_s8(v, bias, device, scale=scale)
+                        continue
                     self.packed[scope] = ops.pack_conv(v, bias, device, scale=scale, precision=prec)
                 else:
                     self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device, precision=prec)

@@ -32,7 +32,7 @@ BOXES = (0, 7, 19)          # refinement boxes checked per frame
 def _families(descs):
     fam = {}
     for d in descs:
-        k = {1: "direct", 2: "wino2x2_slab", 3: "wino2x2_fused", 4: "wino4x4", 5: "stream"}.get(d.tile_hint, "igemm")
+        k = {1: "direct", 2: "wino2x2_slab", 3: "wino2x2_fused", 4: "wino4x4", 5: "stream", 6: "bf16x3_s8"}.get(d.tile_hint, "igemm")
         fam[k] = fam.get(k, 0) + 1
     return fam
 
@@ -101,7 +101,7 @@ def test_bench_pipeline_object_against_the_oracle(monkeypatch):
             tb, tp, tl, ti = PO.fastrcnn_tail(head[:n, :2], head[:n, 2:6].reshape(n, 1, 4), rois, nh, nw)
             out = stage.net.outputs(p, i)
             assert np.array_equal(out[6], ti), (tag, i)
-            assert np.abs(out[0] - tb).max() < 1e-2 and np.abs(out[1] - tp).max() < 1e-4
+            assert len(out[0]) == len(tb) and (len(tb) == 0 or (np.abs(out[0] - tb).max() < 1e-2 and np.abs(out[1] - tp).max() < 1e-4))
             # across the two nets: all 100 indices shared (measured), the same position for >= 98
             common = len(np.intersect1d(idx, inter["proposal_idx"]))
             same = int(np.sum(idx[:min(n, len(inter["proposal_idx"]))] == inter["proposal_idx"][:n]))

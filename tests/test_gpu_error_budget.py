@@ -40,7 +40,7 @@ def _record(net, rows):
 def _families(descs):
     fam = {}
     for d in descs:
-        k = {1: "direct", 2: "wino2x2_slab", 3: "wino2x2_fused", 4: "wino4x4"}.get(d.tile_hint, "igemm")
+        k = {1: "direct", 2: "wino2x2_slab", 3: "wino2x2_fused", 4: "wino4x4", 5: "stream", 6: "bf16x3_s8"}.get(d.tile_hint, "igemm")
         fam[k] = fam.get(k, 0) + 1
     return fam
 
