@@ -281,10 +281,11 @@ int premvos_pwconv_bf16x3_split_f32(const void* in_split, int32_t in_ps, int64_t
  * LDS-DMA.  d->inp / d->wgt are IGNORED: in_s8 = the S8 input (d->in_ps its pixel stride, d->cin % 8 == 0), wgt_s8 = weights
  * packed as bf16 [cout_pad][kh*kw][ceil(cin/32)][4 groups][hi 8 | lo 8], zero padded (premvos_amd.ops.pack_conv_s8).
  * Outputs, each optional (at least one): d->out (fp32 NHWC, d->out_ps) and out_s8 (S8, pixel stride out_s8_ps floats' worth) =
- * act(sum + d->bias (+ d->res, fp32)); cout % 8 == 0.  tile: 0 = 256x256 / 8 waves / 2 buffers, 1 = 256x128 / 4 waves / 3 buffers,
+ * act(sum + d->bias (+ d->res, fp32 -- or res_s8, the residual in S8 with pixel stride res_s8_ps: hi + lo, so that a bottleneck
+ * chain needs no fp32 copy of its block outputs)); cout % 8 == 0.  tile: 0 = 256x256 / 8 waves / 2 buffers, 1 = 256x128 / 4 waves / 3 buffers,
  * 2 = 256x128 / 4 waves / 2 buffers, 3 = 256x128 / 8 waves / 3 buffers, 4 = 128x128 / 4 waves / 3 buffers, 5 = 128x128 / 2 buffers. */
 int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* d, const void* in_s8, const void* wgt_s8, void* out_s8,
-                               int32_t out_s8_ps, int32_t tile, void* stream);
+                               int32_t out_s8_ps, const void* res_s8, int32_t res_s8_ps, int32_t tile, void* stream);
 
 /* fp32 NHWC [pixels][in_ps] -> S8 [pixels][out_ps floats' worth] (c channels; a partial last group is zero filled): the entry of an
  * S8 chain whose producer is an fp32 kernel. */

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 10         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
+ABI_VERSION = 11         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ACT_SPLIT_BF16 = 0x100       # premvos_dwconv3x3_f32 / F(4x4) conv: emit {hi, lo} bf16 groups for premvos_pwconv_bf16x3_split_f32
@@ -69,7 +69,7 @@ SIGNATURES = {
                               _i32, _i32, _i32, _i32, _vp],
     "premvos_pwconv_bf16x3_split_f32": [_vp, _i32, C.c_int64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
                                         _i32, _f32, _vp],
-    "premvos_conv_bf16x3_s8_f32": [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _i32, _vp],
+    "premvos_conv_bf16x3_s8_f32": [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp],
     "premvos_split8_f32": [_vp, _i32, _vp, _i32, C.c_int64, _i32, _vp],
     "premvos_resize_bilinear_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "premvos_broadcast_pixel_f32": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],

@@ -89,6 +89,19 @@ __device__ __forceinline__ void store_split8(char* dst, const float4 v0, const f
   *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
   *reinterpret_cast<uint4*>(dst + 16) = make_uint4(q0.x, q0.y, q1.x, q1.y);
 }
+// the inverse: the 32 bytes of a group (a = hi half, b = lo half, as loaded) -> its eight floats hi + lo in (a, b)
+__device__ __forceinline__ void join_split8(float4& a, float4& b) {
+  const unsigned h[4] = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)};
+  const unsigned l[4] = {__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)};
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {      // a bf16 is the upper half of the float with the same value
+    v[2 * j] = __uint_as_float(h[j] << 16) + __uint_as_float(l[j] << 16);
+    v[2 * j + 1] = __uint_as_float(h[j] & 0xffff0000u) + __uint_as_float(l[j] & 0xffff0000u);
+  }
+  a = make_float4(v[0], v[1], v[2], v[3]);
+  b = make_float4(v[4], v[5], v[6], v[7]);
+}
 // four channels = HALF a group (producers whose threads own four channels: depthwise convs, Winograd output transforms):
 // `pixel` = the pixel's first byte (channel 0 of the window), cg = index of the 4-channel unit; two 8-byte stores
 __device__ __forceinline__ void store_split4(char* pixel, const int cg, const float4 v) {

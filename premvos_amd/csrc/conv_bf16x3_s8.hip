@@ -32,13 +32,14 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 struct PremvosS8Args {
   const char* in;          // S8 activations [n][h][w][in_ps floats]
-  const char* wgt;         // packed weights: row stride = taps * kc_tiles * 128 bytes
+  const char* wgt;         // packed weights: row stride = taps * kc32 * 128 bytes
   const float* bias;
   const float* res;        // fp32 residual (optional)
+  const char* res_s8;      // ... or the residual in S8 (hi + lo: x to ~2^-17 relative; saves the producer an fp32 copy of its output)
   float* out;              // fp32 output (optional)
   char* out_s8;            // S8 output (optional)
   long M;
-  int h, w, ho, wo, in_ps, cin_groups, kc_tiles, taps, kw, sh, sw, dh, dw, pt, pl;
+  int h, w, ho, wo, in_ps, cin_groups, kc32, taps, kw, sh, sw, dh, dw, pt, pl;
   int cout, cout_pad, res_ps, out_ps, out_s8_ps, act, n_tiles;
   float slope;
 };
@@ -71,15 +72,23 @@ __device__ __forceinline__ void wait_vm(const int n) {
   }
 }
 
-// BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN), in 32 x 32 MFMA blocks), NSTAGE LDS buffers of (BM + BN) x 128 bytes.
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S8Args p) {
-  constexpr int NW = WM * WN, NT = 64 * NW;
+// BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN), in 32 x 32 MFMA blocks), NSTAGE LDS buffers of (BM + BN) rows x KC channels
+// (KC = 32: 128-byte rows, two 16-deep MFMA steps per stage; KC = 16: 64-byte rows, one step -- half the LDS, so that a 256 x 128
+// tile fits a CU twice and the two workgroups cover each other's barriers, prologues and epilogues).
+template <int BM, int BN, int WM, int WN, int NSTAGE, int KC, int OCC, bool PW>      // OCC: waves per SIMD the register allocation must allow; PW: 1x1 / stride 1 / no padding
+__global__ __launch_bounds__(64 * WM * WN, OCC) void conv_bf16x3_s8_kernel(const S8Args p) {
+  constexpr int NW = WM * WN;
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-  constexpr int STAGE = (BM + BN) * 128;                 // bytes
-  constexpr int APW = BM / 8 / NW, BPW = BN / 8 / NW;    // 1-KiB DMA pieces per wave and stage (8 rows each)
+  constexpr int RB = KC * 4, CPR = RB / 16, RPP = 1024 / RB;      // row bytes, 16-byte chunks per row, rows per 1-KiB DMA piece
+  constexpr int GPT = KC / 8, KSTEPS = KC / 16;                   // channel groups per stage, MFMA steps per stage
+  constexpr int STAGE = (BM + BN) * RB;                           // bytes
+  constexpr int APW = BM / RPP / NW, BPW = BN / RPP / NW;         // DMA pieces per wave and stage
   constexpr int PPW = APW + BPW;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide over the waves");
+  static_assert(KC == 32 || KC == 16, "stage depth");
+  static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "pieces must divide over the waves");
+  // bank swizzle of row r: physical chunk = logical chunk ^ SW(r).  128-byte rows: two rows per 256-byte bank line -> (r >> 1) & 7;
+  // 64-byte rows: four rows per line -> (r >> 2) & 3.  Either way the 16 rows of a ds_read_b128 lane group hit 16 distinct slots.
+  auto SW = [](const int r) { return KC == 32 ? (r >> 1) & 7 : (r >> 2) & 3; };
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: LDS-DMA bases (M0) and wave offsets stay in SGPRs
@@ -91,17 +100,17 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
 
-  // ---- DMA source maps.  Piece q of a stage = rows [8 q, 8 q + 8); lane l lands at row 8 q + (l >> 3), physical chunk l & 7, and
-  // therefore FETCHES logical chunk (l & 7) ^ ((row >> 1) & 7) of that row.
-  const int prow = lane >> 3, pchunk = lane & 7;
+  // ---- DMA source maps.  Piece q of a stage = rows [RPP q, RPP q + RPP); lane l lands at row RPP q + l / CPR, physical chunk l % CPR,
+  // and therefore FETCHES logical chunk (l % CPR) ^ SW(row) of that row.
+  const int prow = lane / CPR, pchunk = lane % CPR;
   long a_base[APW];                 // byte offset of input pixel (img, oy * sh - pt, ox * sw - pl) + the lane's chunk: tap (0, 0), block 0
   int a_iy[APW], a_ix[APW], a_grp[APW];
 #pragma unroll
   for (int i = 0; i < APW; ++i) {
-    const int row = (wave + i * NW) * 8 + prow;
+    const int row = (wave + i * NW) * RPP + prow;
     long m = m0 + row;
     m = m < p.M ? m : p.M - 1;                           // rows past M: clamped, multiplied, never stored
-    const int lc = pchunk ^ ((row >> 1) & 7);
+    const int lc = pchunk ^ SW(row);
     a_grp[i] = lc >> 1;
     const long img = m / ((long)p.ho * p.wo);
     const int rem = (int)(m - img * p.ho * p.wo), oy = rem / p.wo, ox = rem - oy * p.wo;
@@ -110,36 +119,42 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
     a_base[i] = ((img * p.h + a_iy[i]) * p.w + a_ix[i]) * (long)p.in_ps * 4 + lc * 16;      // (may point outside: only used when in range)
   }
   long b_off[BPW];
-  const long wrow = (long)p.taps * p.kc_tiles * 128;
+  const int kct = p.kc32 * (32 / KC);                    // stages per tap (the weights pad every tap to whole 32-channel blocks)
+  const long wrow = (long)p.taps * p.kc32 * 128;
 #pragma unroll
   for (int i = 0; i < BPW; ++i) {
-    const int row = (wave + i * NW) * 8 + prow;
+    const int row = (wave + i * NW) * RPP + prow;
     const int c = n0 + row < p.cout_pad ? n0 + row : p.cout_pad - 1;
-    b_off[i] = c * wrow + (pchunk ^ ((row >> 1) & 7)) * 16;
+    b_off[i] = c * wrow + (pchunk ^ SW(row)) * 16;
   }
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
-  const int tail_groups = p.cin_groups & 3;              // channel groups of a partial last 32-channel block (0: none)
-  // issue() is called for kt = 0, 1, 2, ... in order: (tap row, tap column, channel block) advance as scalars, no division in the loop
+  // The DMA of a stage is issued in two halves (A pieces, B pieces) BETWEEN the MFMA groups of the stage before it: behind a barrier
+  // all waves of a workgroup reach the same point together, and ~20 instructions per piece issued in one block left the matrix pipe
+  // idle for a fifth of every stage (first version: 285 instead of ~330 TFLOP/s-equivalent on the 728-wide layers).
+  // Stages are issued in order kt = 0, 1, 2, ...: (tap row, tap column, channel block) advance as scalars, no division in the loop.
   int i_ct = 0, i_ky = 0, i_kx = 0;
-  auto issue = [&](const int kt, const int buf) {
+  auto issue_a = [&](const int buf) {
     char* sb = lds + buf * STAGE;
     const int dy = i_ky * p.dh, dx = i_kx * p.dw;
-    const long tap_off = ((long)dy * p.w + dx) * p.in_ps * 4 + i_ct * 128;
-    const int lim = (tail_groups != 0 && i_ct == p.kc_tiles - 1) ? tail_groups : 4;
+    const long tap_off = PW ? (long)(i_ct * RB) : ((long)dy * p.w + dx) * p.in_ps * 4 + i_ct * RB;
+    const int lim = p.cin_groups - i_ct * GPT;           // channel groups of the layer left at this stage (>= GPT: the stage is whole)
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
       // in range: the pixel under the tap; else (padding, or a chunk beyond the layer's channels): 16 bytes of zeros
-      const bool ok = ((unsigned)(a_iy[i] + dy) < (unsigned)p.h) & ((unsigned)(a_ix[i] + dx) < (unsigned)p.w) & (a_grp[i] < lim);   // (& not &&: no branches)
-      const long off = a_base[i] + tap_off;
-      const char* src = p.in + off;
+      bool ok = a_grp[i] < lim;
+      if (!PW) ok = ok & ((unsigned)(a_iy[i] + dy) < (unsigned)p.h) & ((unsigned)(a_ix[i] + dx) < (unsigned)p.w);   // (& not &&: no branches)
+      const char* src = p.in + (a_base[i] + tap_off);
       src = ok ? src : zero;
       dma16(src, sb + (wave + i * NW) * 1024);
     }
-    const char* wb = p.wgt + (long)kt * 128;
+  };
+  auto issue_b = [&](const int kt, const int buf) {
+    char* sb = lds + buf * STAGE;
+    const char* wb = p.wgt + (long)kt * RB;
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
-      dma16(wb + b_off[i], sb + BM * 128 + (wave + i * NW) * 1024);
-    if (++i_ct == p.kc_tiles) {
+      dma16(wb + b_off[i], sb + BM * RB + (wave + i * NW) * 1024);
+    if (++i_ct == kct) {
       i_ct = 0;
       if (++i_kx == p.kw) {
         i_kx = 0;
@@ -158,53 +173,46 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
 
   // ---- fragment addresses: row (lane & 31) of a 32-row block, logical chunk 2 (2 s + (lane >> 5)) + part; the swizzle term depends
   // on lane & 31 only (block origins are multiples of 32 rows)
-  const int frow = lane & 31, fsw = (frow >> 1) & 7, fg = lane >> 5;
-  int foff[2][2];
+  const int frow = lane & 31, fsw = SW(frow), fg = lane >> 5;
+  int foff[KSTEPS][2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-    for (int part = 0; part < 2; ++part) foff[s][part] = frow * 128 + (((2 * (2 * s + fg) + part) ^ fsw) << 4);
-  const int fa_base = wm * (BM / WM) * 128, fb_base = BM * 128 + wn * (BN / WN) * 128;
+    for (int part = 0; part < 2; ++part) foff[s][part] = frow * RB + (((2 * (2 * s + fg) + part) ^ fsw) << 4);
+  const int fa_base = wm * (BM / WM) * RB, fb_base = BM * RB + wn * (BN / WN) * RB;
 
-  auto compute = [&](const int buf) {
-    const char* sb = lds + buf * STAGE;
+  bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+  auto frags = [&](const char* sb, const int s) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        bh[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fb_base + ni * 32 * 128 + foff[s][0]));
-        bl[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fb_base + ni * 32 * 128 + foff[s][1]));
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        ah[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fa_base + mi * 32 * 128 + foff[s][0]));
-        al[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fa_base + mi * 32 * 128 + foff[s][1]));
-      }
-      // small terms first; an accumulator is touched again MI * NI MFMAs later, never in the next instruction
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+    for (int ni = 0; ni < NI; ++ni) {
+      bh[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fb_base + ni * 32 * RB + foff[s][0]));
+      bl[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fb_base + ni * 32 * RB + foff[s][1]));
     }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ah[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fa_base + mi * 32 * RB + foff[s][0]));
+      al[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fa_base + mi * 32 * RB + foff[s][1]));
+    }
+  };
+  // one product term of a 16-deep step over the wave's MI x NI blocks: an accumulator is touched again MI * NI MFMAs later
+  auto term = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
   };
 
   // ---- the K loop: stage kt is multiplied out of buffer kt % NSTAGE while the DMA of stages kt + 1 .. kt + NSTAGE - 1 is in flight.
   // Top of iteration kt: wait until this wave's pieces of stage kt have landed (PPW x (stages issued behind it) may stay in
   // flight), then ONE barrier: every wave's pieces are in, and every wave is done reading buffer (kt - 1) % NSTAGE -- which is the
-  // buffer the next DMA (stage kt + NSTAGE - 1) overwrites.
-  const int KT = p.taps * p.kc_tiles;
+  // buffer the next DMA (stage kt + NSTAGE - 1) overwrites.  Per 16-deep step: lo.hi, hi.lo, hi.hi (small terms first).
+  const int KT = p.taps * kct;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < KT) issue(s, s);
+    if (s < KT) {
+      issue_a(s);
+      issue_b(s, s);
+    }
   int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
     const int behind = KT - 1 - kt < NSTAGE - 2 ? KT - 1 - kt : NSTAGE - 2;      // stages issued after stage kt so far
@@ -214,14 +222,26 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
     // (lgkmcnt(0): this wave's fragment reads of the buffer the next DMA overwrites have returned -- they fed MFMAs that were
     //  issued already, so the wait is free; it makes the write-after-read order architectural instead of a matter of latencies)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + NSTAGE - 1 < KT) {
-      int nb = buf + NSTAGE - 1;
-      nb = nb >= NSTAGE ? nb - NSTAGE : nb;
-      issue(kt + NSTAGE - 1, nb);
+    const bool more = kt + NSTAGE - 1 < KT;
+    int nb = buf + NSTAGE - 1;
+    nb = nb >= NSTAGE ? nb - NSTAGE : nb;
+    const char* sb = lds + buf * STAGE;
+    frags(sb, 0);
+    term(al, bh);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) issue_a(nb);
+    __builtin_amdgcn_sched_barrier(0);
+    term(ah, bl);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) issue_b(kt + NSTAGE - 1, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    term(ah, bh);
+    if (KSTEPS == 2) {
+      frags(sb, KSTEPS - 1);
+      term(al, bh);
+      term(ah, bl);
+      term(ah, bh);
     }
-    __builtin_amdgcn_s_setprio(1);
-    compute(buf);
-    __builtin_amdgcn_s_setprio(0);
     buf = buf + 1 == NSTAGE ? 0 : buf + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // the operand buffers become the epilogue's staging blocks
@@ -257,6 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
     __builtin_amdgcn_wave_barrier();                       // (a wave's LDS instructions execute in order: no fence needed)
     const long mrow0 = m0 + wm * (BM / WM) + mi * 32;
     float4 r0[UNITS], r1[UNITS];
+    const bool has_res = p.res != nullptr || p.res_s8 != nullptr;
     if (p.res != nullptr) {                                // all residual requests of the pass go out before anything waits for one
 #pragma unroll
       for (int i = 0; i < UNITS; ++i) {
@@ -264,6 +285,15 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
         m = m < p.M ? m : p.M - 1;
         r0[i] = premvos::ld4(p.res + m * p.res_ps + colc);
         r1[i] = premvos::ld4(p.res + m * p.res_ps + colc + 4);
+      }
+    } else if (p.res_s8 != nullptr) {                      // {hi8, lo8}: the raw 32 bytes now, hi + lo when they are used
+#pragma unroll
+      for (int i = 0; i < UNITS; ++i) {
+        long m = mrow0 + urow0 + i * RSTEP;
+        m = m < p.M ? m : p.M - 1;
+        const float* g = reinterpret_cast<const float*>(p.res_s8 + (m * p.res_ps + colc) * 4);
+        r0[i] = premvos::ld4(g);
+        r1[i] = premvos::ld4(g + 4);
       }
     }
 #pragma unroll
@@ -274,7 +304,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
       float4 v1 = *reinterpret_cast<const float4*>(stg + row * SC + c8 * 8 + 4);
       v0.x += bv0.x; v0.y += bv0.y; v0.z += bv0.z; v0.w += bv0.w;
       v1.x += bv1.x; v1.y += bv1.y; v1.z += bv1.z; v1.w += bv1.w;
-      if (p.res != nullptr) {
+      if (p.res_s8 != nullptr) premvos::join_split8(r0[i], r1[i]);       // -> the eight floats hi + lo
+      if (has_res) {
         v0.x += r0[i].x; v0.y += r0[i].y; v0.z += r0[i].z; v0.w += r0[i].w;
         v1.x += r1[i].x; v1.y += r1[i].y; v1.z += r1[i].z; v1.w += r1[i].w;
       }
@@ -293,13 +324,15 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_bf16x3_s8_kernel(const S
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int KC = 32, int OCC = 1>
 int launch(const S8Args& a0, hipStream_t s) {
-  constexpr int LDS_BYTES = NSTAGE * (BM + BN) * 128;
+  constexpr int LDS_BYTES = NSTAGE * (BM + BN) * KC * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static_assert(WM * WN * 32 * (32 * (BN / WN / 32) + 4) * 4 <= LDS_BYTES, "epilogue staging must fit the operand buffers");
   static const bool attr_done = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_s8_kernel<BM, BN, WM, WN, NSTAGE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_s8_kernel<BM, BN, WM, WN, NSTAGE, KC, OCC, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_s8_kernel<BM, BN, WM, WN, NSTAGE, KC, OCC, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     return true;
   }();
@@ -307,8 +340,13 @@ int launch(const S8Args& a0, hipStream_t s) {
   S8Args a = a0;
   a.n_tiles = premvos::cdiv(a.cout, BN);
   const long m_tiles = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL((conv_bf16x3_s8_kernel<BM, BN, WM, WN, NSTAGE>), dim3((unsigned)(m_tiles * a.n_tiles)), dim3(64 * WM * WN), LDS_BYTES,
-                     s, a);
+  const bool pw = a.taps == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 && a.h == a.ho && a.w == a.wo;
+  if (pw)
+    hipLaunchKernelGGL((conv_bf16x3_s8_kernel<BM, BN, WM, WN, NSTAGE, KC, OCC, true>), dim3((unsigned)(m_tiles * a.n_tiles)), dim3(64 * WM * WN),
+                       LDS_BYTES, s, a);
+  else
+    hipLaunchKernelGGL((conv_bf16x3_s8_kernel<BM, BN, WM, WN, NSTAGE, KC, OCC, false>), dim3((unsigned)(m_tiles * a.n_tiles)), dim3(64 * WM * WN),
+                       LDS_BYTES, s, a);
   return premvos::check_launch("conv_bf16x3_s8");
 }
 
@@ -347,7 +385,7 @@ extern "C" int premvos_split8_f32(const float* in, int32_t in_ps, void* out_s8, 
 }
 
 extern "C" int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* dp, const void* in_s8, const void* wgt_s8, void* out_s8,
-                                          int32_t out_s8_ps, int32_t tile, void* stream) {
+                                          int32_t out_s8_ps, const void* res_s8, int32_t res_s8_ps, int32_t tile, void* stream) {
   PV_REQUIRE(dp != nullptr && in_s8 != nullptr && wgt_s8 != nullptr, "conv_bf16x3_s8: null pointer");
   const premvos_conv_desc& d = *dp;
   PV_REQUIRE(d.out != nullptr || out_s8 != nullptr, "conv_bf16x3_s8: no output");
@@ -361,16 +399,19 @@ extern "C" int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* dp, const voi
              "conv_bf16x3_s8: S8 output: out_s8_ps %% 8 == 0, 32-byte aligned channel window");
   PV_REQUIRE(d.res == nullptr || (d.res_ps % 4 == 0 && d.res_ps >= d.cout && premvos::aligned16(d.res)), "conv_bf16x3_s8: residual: res_ps %% 4 == 0, 16-byte aligned");
   PV_REQUIRE(d.bias == nullptr || premvos::aligned16(d.bias), "conv_bf16x3_s8: bias must be 16-byte aligned");
+  PV_REQUIRE(res_s8 == nullptr || (d.res == nullptr && res_s8_ps % 8 == 0 && res_s8_ps >= d.cout && (reinterpret_cast<uintptr_t>(res_s8) & 31u) == 0),
+             "conv_bf16x3_s8: an S8 residual excludes an fp32 one; res_s8_ps %% 8 == 0, 32-byte aligned channel window");
   PV_REQUIRE(d.act == PREMVOS_ACT_NONE || d.act == PREMVOS_ACT_RELU || d.act == PREMVOS_ACT_LEAKY, "conv_bf16x3_s8: bad activation");
   PV_REQUIRE(d.out_mode == PREMVOS_OUT_NHWC, "conv_bf16x3_s8: NHWC output only");
   S8Args a;
   a.in = static_cast<const char*>(in_s8);
   a.wgt = static_cast<const char*>(wgt_s8);
   a.bias = d.bias; a.res = d.res; a.out = d.out; a.out_s8 = static_cast<char*>(out_s8);
+  a.res_s8 = static_cast<const char*>(res_s8);
   a.M = (long)d.n * d.ho * d.wo;
-  a.h = d.h; a.w = d.w; a.ho = d.ho; a.wo = d.wo; a.in_ps = d.in_ps; a.cin_groups = d.cin / 8; a.kc_tiles = (d.cin + 31) / 32;
+  a.h = d.h; a.w = d.w; a.ho = d.ho; a.wo = d.wo; a.in_ps = d.in_ps; a.cin_groups = d.cin / 8; a.kc32 = (d.cin + 31) / 32;
   a.taps = d.kh * d.kw; a.kw = d.kw; a.sh = d.sh; a.sw = d.sw; a.dh = d.dh; a.dw = d.dw; a.pt = d.pt; a.pl = d.pl;
-  a.cout = d.cout; a.cout_pad = d.cout_pad; a.res_ps = d.res_ps; a.out_ps = d.out_ps; a.out_s8_ps = out_s8_ps; a.act = d.act;
+  a.cout = d.cout; a.cout_pad = d.cout_pad; a.res_ps = res_s8 != nullptr ? res_s8_ps : d.res_ps; a.out_ps = d.out_ps; a.out_s8_ps = out_s8_ps; a.act = d.act;
   a.n_tiles = 0; a.slope = d.slope;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (tile) {
@@ -380,6 +421,10 @@ extern "C" int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* dp, const voi
     case 3: return launch<256, 128, 4, 2, 3>(a, s);       // eight waves of 64 x 64
     case 4: return launch<128, 128, 2, 2, 3>(a, s);       // four waves of 64 x 64, 96 KB: small layers
     case 5: return launch<128, 128, 2, 2, 2>(a, s);       // 64 KB: two workgroups per CU
+    case 6: return launch<256, 128, 2, 2, 3, 16, 2>(a, s);   // 64-byte rows: 3 x 24 KB, two workgroups of four waves per CU
+    case 7: return launch<256, 128, 2, 2, 2, 16, 2>(a, s);   // 2 x 24 KB
+    case 8: return launch<128, 256, 2, 2, 3, 16, 2>(a, s);   // the transposed wave tile (64 x 128 per wave)
+    case 9: return launch<256, 64, 4, 1, 3, 32>(a, s);    // narrow layers (cout <= 64): four waves of 64 x 64, 3 x 40 KB
     default: return premvos::fail(PREMVOS_EINVAL, "conv_bf16x3_s8: unknown tile %d", tile);
   }
 }

@@ -982,4 +982,4 @@ extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* 
   return premvos::check_launch("mfma_f32_calibrate");
 }
 
-extern "C" int premvos_abi_version(void) { return 10; }   // bump with every change of include/premvos_hip.h
+extern "C" int premvos_abi_version(void) { return 11; }   // bump with every change of include/premvos_hip.h

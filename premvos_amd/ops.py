@@ -688,7 +688,8 @@ def conv_s8_desc(x: NHWC, pk: PackedConvS8, out: Optional[NHWC], out_s8: Optiona
                  act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None) -> ConvDesc:
     """Geometry / epilogue descriptor of one S8 conv launch (premvos_conv_bf16x3_s8_f32); the output size comes from the outputs."""
     o = out if out is not None else out_s8
-    assert x.layout == "s8" and x.c == pk.cin and x.c % 8 == 0 and x.coff % 8 == 0, (x.layout, x.c, pk.cin, x.coff)
+    # (an S8 window may carry up to 7 zero channels behind the layer's own: the packed weights are zero there)
+    assert x.layout == "s8" and x.c == _r(pk.cin, 8) and x.coff % 8 == 0, (x.layout, x.c, pk.cin, x.coff)
     assert o is not None and o.c == pk.cout and o.n == x.n and pk.cout % 8 == 0
     assert out is None or out.layout == "f32"
     assert out_s8 is None or (out_s8.layout == "s8" and (out_s8.n, out_s8.h, out_s8.w, out_s8.c) == (o.n, o.h, o.w, o.c) and out_s8.coff % 8 == 0)
@@ -726,22 +727,27 @@ def s8_tile_rule(m: int, cout: int) -> int:
     return 4
 
 
-def conv_s8(x: NHWC, pk: PackedConvS8, out: Optional[NHWC] = None, out_s8: Optional[NHWC] = None, tile: Optional[int] = None, **kw):
+def conv_s8(x: NHWC, pk: PackedConvS8, out: Optional[NHWC] = None, out_s8: Optional[NHWC] = None, tile: Optional[int] = None,
+            res_s8: Optional[NHWC] = None, **kw):
     d = conv_s8_desc(x, pk, out, out_s8, **kw)
-    run_s8(d, x, pk, out_s8, tile)
+    run_s8(d, x, pk, out_s8, tile, res_s8=res_s8)
     return out if out is not None else out_s8
 
 
-def run_s8(d: ConvDesc, x: NHWC, pk: PackedConvS8, out_s8: Optional[NHWC], tile: Optional[int] = None, stream: Optional[int] = None):
+def run_s8(d: ConvDesc, x: NHWC, pk: PackedConvS8, out_s8: Optional[NHWC], tile: Optional[int] = None, stream: Optional[int] = None,
+           res_s8: Optional[NHWC] = None):
+    """``res_s8``: the residual as an S8 tensor (instead of ``res`` of the descriptor): added as hi + lo."""
     t = s8_tile_rule(d.n * d.ho * d.wo, d.cout) if tile is None else tile
+    assert res_s8 is None or (res_s8.layout == "s8" and res_s8.c == d.cout and res_s8.coff % 8 == 0 and not d.res)
     _lib.check(_lib.load().premvos_conv_bf16x3_s8_f32(C.byref(d), x.ptr, pk.wgt.data_ptr(), out_s8.ptr if out_s8 is not None else None,
-                                                      out_s8.ps if out_s8 is not None else 0, t,
+                                                      out_s8.ps if out_s8 is not None else 0,
+                                                      res_s8.ptr if res_s8 is not None else None, res_s8.ps if res_s8 is not None else 0, t,
                                                       _lib.current_stream() if stream is None else stream), "conv_bf16x3_s8")
 
 
 def split8(x: NHWC, out: NHWC):
     """fp32 NHWC -> S8 (same shape): the entry of an S8 chain whose producer is an fp32 kernel."""
-    assert x.layout == "f32" and out.layout == "s8" and (x.n, x.h, x.w, x.c) == (out.n, out.h, out.w, out.c) and out.coff % 8 == 0
+    assert x.layout == "f32" and out.layout == "s8" and (x.n, x.h, x.w, _r(x.c, 8)) == (out.n, out.h, out.w, out.c) and out.coff % 8 == 0
     _lib.check(_lib.load().premvos_split8_f32(x.ptr, x.ps, out.ptr, out.ps, x.n * x.h * x.w, x.c, _lib.current_stream()), "split8")
     return out
 

@@ -85,19 +85,19 @@ class _Plan:
             keep.append(v)
             return v
 
-        def conv(x, name, out, uid=None, out_s8=None, **kw):
-            """``x`` in the resident split layout S8 (bf16x3 mode) -> csrc/conv_bf16x3_s8.hip (fp32 ``out`` and / or S8 ``out_s8``);
-            fp32 ``x`` -> premvos_conv2d_f32."""
+        def conv(x, name, out, uid=None, out_s8=None, res_s8=None, **kw):
+            """``x`` in the resident split layout S8 (bf16x3 mode) -> csrc/conv_bf16x3_s8.hip (fp32 ``out`` and / or S8 ``out_s8``;
+            ``res_s8``: the residual read from an S8 tensor); fp32 ``x`` -> premvos_conv2d_f32."""
             key = "conv:" + (uid or name)
             if x.layout == "s8":
                 pk = S8[name]
                 d = ops.conv_s8_desc(x, pk, out, out_s8, **kw)
                 d.tile_hint = ops.S8_HINT
                 o = out if out is not None else out_s8
-                steps.append((key, lambda d=d, x=x, pk=pk, o8=out_s8: ops.run_s8(d, x, pk, o8)))
+                steps.append((key, lambda d=d, x=x, pk=pk, o8=out_s8, r8=res_s8: ops.run_s8(d, x, pk, o8, res_s8=r8)))
                 self.split_layers += 1
             else:
-                assert out_s8 is None
+                assert out_s8 is None and res_s8 is None
                 pk = P[name]
                 d = ops.conv_desc(x, pk, out, **kw)
                 self.tune_descs.append(d)
@@ -120,48 +120,57 @@ class _Plan:
                                                0.0, _lib.current_stream()), "maxpool")
         steps.append(("maxpool", pool))
 
-        def group(x: NHWC, g: int, feat: int, count: int, stride: int, tag: str = "", x8: Optional[NHWC] = None,
-                  last_s8: bool = False):
+        def group(x: Optional[NHWC], g: int, feat: int, count: int, stride: int, tag: str = "", x8: Optional[NHWC] = None,
+                  last_s8: bool = False, last_f32: bool = True):
             """One ResNet group (basemodel.py:62-72).  fp32 mode: every tensor is floats.  bf16x3 mode, groups >= net.s8_from: the
-            bottleneck chain lives in S8 -- conv1 and conv2 write S8 only (one reader each), conv3 = relu(bn(conv3) + shortcut)
-            writes the fp32 block output (the next block's residual, RoIAlign's input) AND its S8 copy (the next conv1's /
-            shortcut conv's / RPN's operand); ``x8``: the S8 copy of ``x`` when the producer already wrote one.  Returns (y, y8)."""
+            bottleneck chain lives in S8 ONLY -- conv1 / conv2 / conv3 read and write S8, the residual of an identity block is
+            read from the previous block's S8 output (hi + lo), a convshortcut's output is fp32 -- and only the last block of a
+            group whose output a float kernel reads (RoIAlign / RPN after group 2, the average pool after conv5: ``last_f32``)
+            also writes floats.  ``x8``: the S8 form of the group's input when the producer wrote one; else one split pass over
+            ``x``.  Returns (y or None, y8 or None)."""
             s8 = net.s8 and g >= net.s8_from
+            shape = (x if x is not None else x8)
+            n_, h_, w_, c_ = shape.n, shape.h, shape.w, shape.c
             for i in range(count):
                 p = f"group{g}/block{i}"
                 s = stride if i == 0 else 1
+                last = i + 1 == count
                 if s8 and x8 is None:                   # entry of the chain: one split pass over the fp32 tensor
-                    x8 = alloc_s8(x.n, x.h, x.w, x.c)
+                    x8 = alloc_s8(n_, h_, w_, c_)
                     steps.append((f"split8:{tag}{p}", lambda i_=x, o_=x8: ops.split8(i_, o_)))
                 xin = x8 if s8 else x
                 mk = alloc_s8 if s8 else alloc
-                t1 = mk(x.n, x.h, x.w, feat)
+                t1 = mk(n_, h_, w_, feat)
                 o1 = dict(out=None, out_s8=t1) if s8 else dict(out=t1)
                 conv(xin, p + "/conv1", uid=tag + p + "/conv1", act=ACT_RELU, **o1)
                 if s == 2:        # pad [0,1] + VALID stride 2  (basemodel.py:54-56)
-                    ho, wo = ops.out_size(x.h, 3, 2, 0, 1), ops.out_size(x.w, 3, 2, 0, 1)
-                    t2 = mk(x.n, ho, wo, feat)
+                    ho, wo = ops.out_size(h_, 3, 2, 0, 1), ops.out_size(w_, 3, 2, 0, 1)
+                    t2 = mk(n_, ho, wo, feat)
                     o2 = dict(out=None, out_s8=t2) if s8 else dict(out=t2)
                     conv(t1, p + "/conv2", uid=tag + p + "/conv2", stride=(2, 2), pad=(0, 0), act=ACT_RELU, **o2)
                 else:
-                    t2 = mk(x.n, x.h, x.w, feat)
+                    ho, wo = h_, w_
+                    t2 = mk(n_, h_, w_, feat)
                     o2 = dict(out=None, out_s8=t2) if s8 else dict(out=t2)
                     conv(t1, p + "/conv2", uid=tag + p + "/conv2", pad=(1, 1), act=ACT_RELU, **o2)
+                res, res8 = x, None
                 if p + "/convshortcut" in P or p + "/convshortcut" in S8:   # 1x1 stride s on x[:, :, :-1, :-1] == reading pixel (s*oy, s*ox)
-                    sc = alloc(x.n, t2.h, t2.w, feat * 4)
-                    conv(xin, p + "/convshortcut", sc, uid=tag + p + "/convshortcut", stride=(s, s))
-                else:
-                    sc = x
-                y = alloc(x.n, t2.h, t2.w, feat * 4)
-                y8 = alloc_s8(x.n, t2.h, t2.w, feat * 4) if s8 and (i + 1 < count or last_s8) else None
-                conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", out_s8=y8, res=sc, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
-                x, x8 = y, y8
+                    res = alloc(n_, ho, wo, feat * 4)
+                    conv(xin, p + "/convshortcut", res, uid=tag + p + "/convshortcut", stride=(s, s))
+                elif s8:
+                    res, res8 = None, x8
+                want_f32 = not s8 or (last and last_f32)
+                y = alloc(n_, ho, wo, feat * 4) if want_f32 else None
+                y8 = alloc_s8(n_, ho, wo, feat * 4) if s8 and (not last or last_s8) else None
+                conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", out_s8=y8, res=res, res_s8=res8, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
+                x, x8, h_, w_, c_ = y, y8, ho, wo, feat * 4
             return x, x8
 
         nb = net.num_blocks
-        x, x8 = group(x, 0, 64, nb[0], 1, last_s8=net.s8 and net.s8_from <= 0)
-        x, x8 = group(x, 1, 128, nb[1], 2, x8=x8, last_s8=net.s8 and net.s8_from <= 1)
-        fm, fm8 = group(x, 2, 256, nb[2], 2, x8=x8, last_s8=net.s8)
+        s8g = [net.s8 and g >= net.s8_from for g in range(4)]
+        x, x8 = group(x, 0, 64, nb[0], 1, last_s8=s8g[1], last_f32=not s8g[1])
+        x, x8 = group(x, 1, 128, nb[1], 2, x8=x8, last_s8=s8g[2], last_f32=not s8g[2])
+        fm, fm8 = group(x, 2, 256, nb[2], 2, x8=x8, last_s8=net.s8 and net.s8_rpn)
         self.featuremap = fm
         fh, fw = fm.h, fm.w
         # rpn_head (model.py:30-51): 3x3 + ReLU, then class(15) + box(60) as one 1x1 conv
@@ -282,10 +291,13 @@ class ProposalNet:
                 self.packed_s8[name] = ops.pack_conv_s8(w[name + "/W"], bias, device, scale=scale)
             else:       # (with S8 chains: conv0 / the HBM-bound group-0 layers stay on the fp32 kernels the shipped table tunes)
                 self.packed[name] = ops.pack_conv(w[name + "/W"], bias, device, scale=scale, precision="fp32" if self.s8 else prec)
-        if self.s8:
+        # the RPN 3x3 (1024 -> 1024, K = 9216) stays on fp32 Winograd F(4x4,3x3) by default: 4x fewer multiplies = 456 ... 467
+        # TFLOP/s-equivalent against ~400 for three bf16 MFMAs per product on this shape (profiles/r04_s8_bench.txt); PREMVOS_S8_RPN=1
+        self.s8_rpn = os.environ.get("PREMVOS_S8_RPN", "0") == "1"
+        if self.s8 and self.s8_rpn:
             self.packed_s8["rpn/conv0"] = ops.pack_conv_s8(w["rpn/conv0/W"], w["rpn/conv0/b"], device)
         else:
-            self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device, precision=prec)
+            self.packed["rpn/conv0"] = ops.pack_conv(w["rpn/conv0/W"], w["rpn/conv0/b"], device, precision="fp32" if self.s8 else prec)
         self.packed["rpn/heads"] = ops.pack_conv(torch.cat([w["rpn/class/W"], w["rpn/box/W"]], 0),
                                                  torch.cat([w["rpn/class/b"], w["rpn/box/b"]], 0), device, precision=prec)
         hw = torch.cat([w["fastrcnn/class/W"], w["fastrcnn/box/W"], w["secondclassification/class/W"]], 0)

@@ -154,7 +154,8 @@ class _Plan:
             steps.append((f"dw:{name}", f))
             self.dw_bytes[f"dw:{name}"] = 4.0 * k.c * (x.n * x.h * x.w + out.n * out.h * out.w)
 
-        alloc_mid = alloc_s8 if split_pw else alloc             # the tensor between the two halves of a separable conv
+        def alloc_mid(n, h, w, c, name=None):                   # the tensor between the two halves of a separable conv: S8 when its
+            return alloc_s8(n, h, w, c) if split_pw and (name is None or name in S8) else alloc(n, h, w, c)   # pointwise half runs on the S8 kernel
 
         S = INPUT_SIZE
         self.frames = torch.zeros((G, H, W, 3), dtype=torch.uint8, device=dev)
@@ -188,18 +189,29 @@ class _Plan:
         release(c11)
 
         skip_feat: Optional[NHWC] = None
-        for prefix, cin, depths, skip, relu_in, stride, rate in module_plan(net.num_middle):
+        mods = module_plan(net.num_middle)
+        x8: Optional[NHWC] = None          # S8 copy of x (bf16x3 mode) when the next consumer is a conv: a shortcut conv / ASPP's 1x1 branch
+        for mi_, (prefix, cin, depths, skip, relu_in, stride, rate) in enumerate(mods):
             inp, cur = x, x
             act = ACT_RELU if relu_in else ACT_NONE
             sc = None
             if skip == "conv":
                 ho = ops.out_size(inp.h, 1, stride, 0, 0)
                 sc = alloc(P, ho, ho, depths[-1])
-                conv(inp, prefix + "/shortcut", sc, stride=(stride, stride))
+                on_s8 = split_pw and prefix + "/shortcut" in S8
+                if on_s8 and x8 is None:               # (its producer ran on an fp32 kernel: one split pass)
+                    x8 = alloc_s8(P, inp.h, inp.w, inp.c)
+                    steps.append((f"split8:{prefix}", lambda i_=inp, o_=x8: ops.split8(i_, o_)))
+                conv(x8 if on_s8 else inp, prefix + "/shortcut", sc, stride=(stride, stride))
+            if x8 is not None:
+                release(x8)
+                x8 = None
+            # does the NEXT consumer of this module's output multiply it (shortcut conv of the next module, aspp0 after the last)?
+            want8 = split_pw and ((mods[mi_ + 1][3] == "conv" and mods[mi_ + 1][0] + "/shortcut" in S8) if mi_ + 1 < len(mods) else True)
             for i, d in enumerate(depths):
                 s = stride if i == 2 else 1
                 ho = ops.out_size(cur.h, 3, s, rate, rate, rate)
-                t = alloc_mid(P, ho, ho, cur.c)
+                t = alloc_mid(P, ho, ho, cur.c, f"{prefix}/separable_conv{i + 1}_pointwise")
                 dwconv(cur, f"{prefix}/separable_conv{i + 1}_depthwise", t, stride=s, rate=rate, pre_relu=not relu_in,
                        act=act)
                 o = alloc(P, ho, ho, d)
@@ -208,7 +220,9 @@ class _Plan:
                     res = sc
                 elif i == 2 and skip == "sum":
                     res = inp
-                conv(t, f"{prefix}/separable_conv{i + 1}_pointwise", o, act=act, res=res)
+                if i == 2 and want8 and t.layout == "s8":
+                    x8 = alloc_s8(P, ho, ho, d)
+                conv(t, f"{prefix}/separable_conv{i + 1}_pointwise", o, out_s8=x8 if i == 2 else None, act=act, res=res)
                 release(t)
                 if cur is not inp:
                     if f"{prefix}/separable_conv{i}" == DECODER_SKIP:
@@ -237,9 +251,7 @@ class _Plan:
             i.ptr, i.ps, i.n, 256, o.ptr, o.ps, o.h, o.w, _lib.current_stream()), "broadcast")))
         if cat8:       # the S8 concat buffer: the broadcast and the (fp32-input) 1x1 branch go through an fp32 block and are split once
             steps.append(("split8:image_pooling", lambda i=bc, o=cat.slice(0, 256): ops.split8(i, o)))
-            a0 = alloc(P, fh, fh, 256)
-            conv(feat, "aspp0", a0, act=ACT_RELU)
-            steps.append(("split8:aspp0", lambda i=a0, o=cat.slice(256, 256): ops.split8(i, o)))
+            conv(x8, "aspp0", None, cat.slice(256, 256), act=ACT_RELU)        # (x8: the S8 copy exit_flow's last conv wrote)
         else:
             conv(feat, "aspp0", cat.slice(256, 256), act=ACT_RELU)
         for i, r in enumerate(ATROUS_RATES, 1):
@@ -263,7 +275,7 @@ class _Plan:
         conv(skip_feat, "decoder/feature_projection0", dcat.slice(256, 48), act=ACT_RELU)
         d = dcat
         for j in (0, 1):
-            t = alloc_mid(P, dh, dh, d.c)
+            t = alloc_mid(P, dh, dh, d.c, f"decoder/decoder_conv{j}_pointwise")
             dwconv(d, f"decoder/decoder_conv{j}_depthwise", t, act=ACT_RELU)
             o = alloc(P, dh, dh, 256)
             conv(t, f"decoder/decoder_conv{j}_pointwise", o, act=ACT_RELU)
@@ -344,14 +356,20 @@ class RefinementNet:
             elif k.endswith("/weights"):
                 if scope + "/BatchNorm" in weights:
                     scale, bias = _fold(weights[scope + "/BatchNorm"], eps)
-                    s8 = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" and \
-                        (scope.endswith("_pointwise") or scope == "concat_projection")
+                    # bf16x3 mode: the 1x1 convs with K >= PREMVOS_S8_MIN_CIN (256) input channels run on the S8 kernel; the short-K
+                    # layers of the entry flow are HBM-bound (the fp32 streaming kernel moves them at 4.7 TB/s: 0.98 ms for the 64 -> 128
+                    # layer at 193 x 193 against 2.4 ms on a 256-row MFMA tile with two K stages) and, like the dense 3x3 stem,
+                    # stay on the fp32 kernels the shipped table tunes
+                    on_s8 = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0"
+                    s8 = on_s8 and v.shape[1] >= int(os.environ.get("PREMVOS_S8_MIN_CIN", "256")) and v.shape[0] % 8 == 0 and \
+                        (scope.endswith("_pointwise") or scope.endswith("/shortcut") or scope in ("concat_projection", "aspp0"))
                     if s8:
                         self.packed_s8[scope] = ops.pack_conv_s8(v, bias, device, scale=scale)
                         continue
-                    self.packed[scope] = ops.pack_conv(v, bias, device, scale=scale, precision=prec)
+                    self.packed[scope] = ops.pack_conv(v, bias, device, scale=scale, precision="fp32" if on_s8 else prec)
                 else:
-                    self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device, precision=prec)
+                    on_s8 = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0"
+                    self.packed[scope] = ops.pack_conv(v, weights.get(scope + "/biases"), device, precision="fp32" if on_s8 else prec)
 
     def plan(self, P: int, H: int, W: int, with_posterior: bool = False, lane: int = 0, frames: int = 1,
              packed: bool = False) -> _Plan:

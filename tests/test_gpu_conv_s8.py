@@ -43,7 +43,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", list(range(10)))
 def test_conv_s8_matches_the_fp64_convolution(case, tile):
     ops = _ops()
     cin, cout, k, stride, dil, pad, n, h, w, res, act = case
@@ -98,7 +98,7 @@ def test_conv_s8_tiles_are_bit_identical_and_chain():
     w3 = torch.randn((256, 64, 1, 1), generator=g) * (1.0 / 64) ** 0.5
     xin = _to_s8(x, ops)
     outs = []
-    for tile in range(6):
+    for tile in range(10):
         o = ops.NHWC.alloc(2, 19, 27, 64)
         ops.conv_s8(xin, ops.pack_conv_s8(w1, None), o, None, tile=tile, act=ops.ACT_RELU)
         torch.cuda.synchronize()
@@ -112,6 +112,11 @@ def test_conv_s8_tiles_are_bit_identical_and_chain():
     torch.cuda.synchronize()
     ref = F.relu(F.conv2d(F.relu(F.conv2d(F.relu(F.conv2d(x.double(), w1.double())), w2.double(), padding=1)), w3.double()) + x.double())
     assert (y.torch().cpu().double() - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+    # the same block with the residual read from the S8 tensor (hi + lo) and an S8-only output: what the ResNet chains run
+    y8 = ops.NHWC.alloc_s8(2, 19, 27, 256)
+    ops.conv_s8(t2, ops.pack_conv_s8(w3, None), None, y8, res_s8=xin, act=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert (y8.torch().cpu().double() - ref).abs().max().item() < 8e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_conv_s8_refuses_what_it_does_not_cover():
