@@ -72,6 +72,88 @@ __device__ __forceinline__ void wait_vm(const int n) {
   }
 }
 
+// The epilogue of a wave: its MI x NI accumulator blocks (rows m_base + 32 mi + ..., columns n_base + 32 ni + ...) -> bias, residual
+// (fp32 or S8), activation -> fp32 NHWC and / or S8, wave-private: MI passes of 32 rows x (32 NI) columns through this wave's LDS
+// block; a lane owns 8 consecutive columns (one S8 group) of a row per unit.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue(const S8Args& p, f32x16 (&acc)[MI][NI], char* lds, const int wave, const int lane, const long m_base,
+                                         const int n_base) {
+  constexpr int WC = 32 * NI, SC = WC + 4, UNITS = 32 * (WC / 8) / 64, RSTEP = 64 / (WC / 8);
+  float* stg = reinterpret_cast<float*>(lds) + wave * (32 * SC);
+  const int c8 = lane % (WC / 8), urow0 = lane / (WC / 8);
+  const int col = n_base + c8 * 8;
+  const bool col_ok = col < p.cout;                       // (cout % 8 == 0 is required by the launcher)
+  const int colc = col_ok ? col : 0;
+  float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
+  if (p.bias != nullptr) {
+    bv0 = premvos::ld4(p.bias + colc);
+    bv1 = premvos::ld4(p.bias + colc + 4);
+  }
+  const int act = p.act;
+  auto activate = [&](float x) {
+    if (act == PREMVOS_ACT_RELU) return x > 0.f ? x : 0.f;
+    if (act == PREMVOS_ACT_LEAKY) return x > 0.f ? x : x * p.slope;
+    return x;
+  };
+#pragma unroll               // (fully unrolled: a runtime index into acc[][] would put the accumulators into scratch memory)
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        stg[row * SC + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+      }
+    __builtin_amdgcn_wave_barrier();                       // (a wave's LDS instructions execute in order: no fence needed)
+    const long mrow0 = m_base + mi * 32;
+    float4 r0[UNITS], r1[UNITS];
+    const bool has_res = p.res != nullptr || p.res_s8 != nullptr;
+    if (p.res != nullptr) {                                // all residual requests of the pass go out before anything waits for one
+#pragma unroll
+      for (int i = 0; i < UNITS; ++i) {
+        long m = mrow0 + urow0 + i * RSTEP;
+        m = m < p.M ? m : p.M - 1;
+        r0[i] = premvos::ld4(p.res + m * p.res_ps + colc);
+        r1[i] = premvos::ld4(p.res + m * p.res_ps + colc + 4);
+      }
+    } else if (p.res_s8 != nullptr) {                      // {hi8, lo8}: the raw 32 bytes now, hi + lo when they are used
+#pragma unroll
+      for (int i = 0; i < UNITS; ++i) {
+        long m = mrow0 + urow0 + i * RSTEP;
+        m = m < p.M ? m : p.M - 1;
+        const float* g = reinterpret_cast<const float*>(p.res_s8 + (m * p.res_ps + colc) * 4);
+        r0[i] = premvos::ld4(g);
+        r1[i] = premvos::ld4(g + 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+      const int row = urow0 + i * RSTEP;
+      const long m = mrow0 + row;
+      float4 v0 = *reinterpret_cast<const float4*>(stg + row * SC + c8 * 8);
+      float4 v1 = *reinterpret_cast<const float4*>(stg + row * SC + c8 * 8 + 4);
+      v0.x += bv0.x; v0.y += bv0.y; v0.z += bv0.z; v0.w += bv0.w;
+      v1.x += bv1.x; v1.y += bv1.y; v1.z += bv1.z; v1.w += bv1.w;
+      if (p.res_s8 != nullptr) premvos::join_split8(r0[i], r1[i]);       // -> the eight floats hi + lo
+      if (has_res) {
+        v0.x += r0[i].x; v0.y += r0[i].y; v0.z += r0[i].z; v0.w += r0[i].w;
+        v1.x += r1[i].x; v1.y += r1[i].y; v1.z += r1[i].z; v1.w += r1[i].w;
+      }
+      v0.x = activate(v0.x); v0.y = activate(v0.y); v0.z = activate(v0.z); v0.w = activate(v0.w);
+      v1.x = activate(v1.x); v1.y = activate(v1.y); v1.z = activate(v1.z); v1.w = activate(v1.w);
+      if (m < p.M && col_ok) {
+        if (p.out != nullptr) {
+          float* o = p.out + m * p.out_ps + col;
+          *reinterpret_cast<float4*>(o) = v0;
+          *reinterpret_cast<float4*>(o + 4) = v1;
+        }
+        if (p.out_s8 != nullptr) premvos::store_split8(p.out_s8 + (m * p.out_s8_ps + col) * 4, v0, v1);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN), in 32 x 32 MFMA blocks), NSTAGE LDS buffers of (BM + BN) rows x KC channels
 // (KC = 32: 128-byte rows, two 16-deep MFMA steps per stage; KC = 16: 64-byte rows, one step -- half the LDS, so that a 256 x 128
 // tile fits a CU twice and the two workgroups cover each other's barriers, prologues and epilogues).
@@ -246,82 +328,149 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_bf16x3_s8_kernel(const
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // the operand buffers become the epilogue's staging blocks
 
-  // ---- epilogue, wave-private: MI passes of 32 rows x (32 NI) columns through this wave's LDS block; a lane owns 8 consecutive
-  // columns (one S8 group) of a row per unit
-  constexpr int WC = 32 * NI, SC = WC + 4, UNITS = 32 * (WC / 8) / 64, RSTEP = 64 / (WC / 8);
-  float* stg = reinterpret_cast<float*>(lds) + wave * (32 * SC);
-  const int c8 = lane % (WC / 8), urow0 = lane / (WC / 8);
-  const int col = n0 + wn * WC + c8 * 8;
-  const bool col_ok = col < p.cout;                       // (cout % 8 == 0 is required by the launcher)
-  const int colc = col_ok ? col : 0;
-  float4 bv0 = make_float4(0.f, 0.f, 0.f, 0.f), bv1 = bv0;
-  if (p.bias != nullptr) {
-    bv0 = premvos::ld4(p.bias + colc);
-    bv1 = premvos::ld4(p.bias + colc + 4);
+  epilogue<MI, NI>(p, acc, lds, wave, lane, m0 + wm * (BM / WM), n0 + wn * (32 * NI));
+}
+
+// ---- The PING-PONG form for pointwise layers (1x1, stride 1): 256 x 256 tile, eight waves as two GROUPS of four (one wave of each
+// group per SIMD), 32-channel stages in two LDS buffers.  In the kernel above all eight waves reach every barrier together: they
+// read fragments together, issue DMA together and then queue for the matrix pipe together -- PMC on the 728-wide layer: 32 % of
+// the wave cycles parked on s_waitcnt / s_barrier, the pipe 38 % busy.  Here the groups run the SAME program one phase apart:
+//
+//     group 0:  | L0 + DMA | M0 | L1 + DMA | M1 | ...          L = all fragment reads of a stage into registers (24 x ds_read_b128),
+//     group 1:  |    -     | L0 | M0       | L1 | M1 | ...     M = its 48 MFMAs, back to back;  | = s_barrier (whole workgroup)
+//
+// so on every SIMD one wave multiplies while its partner loads -- the pipe only waits at the barriers themselves.  Group 0 also
+// issues the stage DMA (16 pieces per wave, behind its fragment reads): stage k + 1 goes into the buffer both groups finished
+// reading one phase ago and is waited for (vmcnt(0)) at the end of group 0's MFMA phase, a full phase before anyone reads it.
+// Same products in the same order as the kernel above: bit-identical results (tests/test_gpu_conv_s8.py).
+__global__ __launch_bounds__(512, 2) void conv_bf16x3_s8_pp_kernel(const S8Args p) {
+  constexpr int BM = 256, BN = 256, MI = 4, NI = 2, RB = 128, STAGE = (BM + BN) * RB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;              // group = wave row: rows [128 grp, +128), columns [64 wn, +64)
+  const int nwg = gridDim.x;
+  const int v = premvos::xcd_contiguous(blockIdx.x, nwg);
+  const int tile_m = v / p.n_tiles, tile_n = v - tile_m * p.n_tiles;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+  auto SW = [](const int r) { return (r >> 1) & 7; };
+
+  // DMA maps of group 0: piece q = wn + 4 i, i < 16: q < 32 -> A rows [8 q, +8), else B rows [8 (q - 32), +8); 32-bit byte offsets
+  // from the kernel-uniform bases (the launcher checks both operands span < 4 GB)
+  const int prow = lane >> 3, pchunk = lane & 7;
+  // (pieces of one wave are 32 rows apart: the swizzle term, hence the logical chunk a lane fetches, is the same for all of them;
+  //  the weight rows are a fixed stride apart -- the packer pads the matrix to whole 256-row tiles -- so one register addresses all
+  //  eight B pieces; the pixel rows keep an offset each, because the last row tile clamps them to the tensor)
+  const int lc = pchunk ^ SW(wn * 8 + prow);
+  const int a_grp = lc >> 1;
+  unsigned a_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    long m = m0 + (wn + 4 * i) * 8 + prow;
+    m = m < p.M ? m : p.M - 1;
+    a_off[i] = (unsigned)(m * p.in_ps * 4 + lc * 16);
   }
-  const int act = p.act;
-  auto activate = [&](float x) {
-    if (act == PREMVOS_ACT_RELU) return x > 0.f ? x : 0.f;
-    if (act == PREMVOS_ACT_LEAKY) return x > 0.f ? x : x * p.slope;
-    return x;
+  const long wrow = (long)p.kc32 * 128;
+  const unsigned b_off0 = (unsigned)((n0 + wn * 8 + prow) * wrow + lc * 16);
+  const unsigned b_step = (unsigned)(32 * wrow);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  auto issue = [&](const int kt, const int buf) {
+    char* sb = lds + buf * STAGE;
+    const bool ok = a_grp < p.cin_groups - kt * 4;       // the layer's last 32-channel block may be partial: absent chunks are zeros
+    const char* ab = p.in + kt * RB;
+    const char* wb = p.wgt + kt * RB + b_off0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const char* src = ab + a_off[i];
+      src = ok ? src : zero;
+      dma16(src, sb + (wn + 4 * i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma16(wb + i * b_step, sb + BM * RB + (wn + 4 * i) * 1024);
   };
-#pragma unroll               // (fully unrolled: a runtime index into acc[][] would put the accumulators into scratch memory)
-  for (int mi = 0; mi < MI; ++mi) {
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        stg[row * SC + ni * 32 + (lane & 31)] = acc[mi][ni][r];
-      }
-    __builtin_amdgcn_wave_barrier();                       // (a wave's LDS instructions execute in order: no fence needed)
-    const long mrow0 = m0 + wm * (BM / WM) + mi * 32;
-    float4 r0[UNITS], r1[UNITS];
-    const bool has_res = p.res != nullptr || p.res_s8 != nullptr;
-    if (p.res != nullptr) {                                // all residual requests of the pass go out before anything waits for one
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  const int frow = lane & 31, fsw = SW(frow), fg = lane >> 5;
+  int foff[2][2];
 #pragma unroll
-      for (int i = 0; i < UNITS; ++i) {
-        long m = mrow0 + urow0 + i * RSTEP;
-        m = m < p.M ? m : p.M - 1;
-        r0[i] = premvos::ld4(p.res + m * p.res_ps + colc);
-        r1[i] = premvos::ld4(p.res + m * p.res_ps + colc + 4);
-      }
-    } else if (p.res_s8 != nullptr) {                      // {hi8, lo8}: the raw 32 bytes now, hi + lo when they are used
+  for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
-      for (int i = 0; i < UNITS; ++i) {
-        long m = mrow0 + urow0 + i * RSTEP;
-        m = m < p.M ? m : p.M - 1;
-        const float* g = reinterpret_cast<const float*>(p.res_s8 + (m * p.res_ps + colc) * 4);
-        r0[i] = premvos::ld4(g);
-        r1[i] = premvos::ld4(g + 4);
+    for (int part = 0; part < 2; ++part) foff[s_][part] = frow * RB + (((2 * (2 * s_ + fg) + part) ^ fsw) << 4);
+  const int fa_base = grp * 128 * RB, fb_base = BM * RB + wn * 64 * RB;
+  bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];                   // [16-deep step][block]
+  auto frags = [&](const char* sb) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        bh[s_][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fb_base + ni * 32 * RB + foff[s_][0]));
+        bl[s_][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fb_base + ni * 32 * RB + foff[s_][1]));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        ah[s_][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fa_base + mi * 32 * RB + foff[s_][0]));
+        al[s_][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + fa_base + mi * 32 * RB + foff[s_][1]));
       }
     }
+  };
+  auto term = [&](const bf16x8 (&a)[MI], const bf16x8 (&b)[NI]) {
 #pragma unroll
-    for (int i = 0; i < UNITS; ++i) {
-      const int row = urow0 + i * RSTEP;
-      const long m = mrow0 + row;
-      float4 v0 = *reinterpret_cast<const float4*>(stg + row * SC + c8 * 8);
-      float4 v1 = *reinterpret_cast<const float4*>(stg + row * SC + c8 * 8 + 4);
-      v0.x += bv0.x; v0.y += bv0.y; v0.z += bv0.z; v0.w += bv0.w;
-      v1.x += bv1.x; v1.y += bv1.y; v1.z += bv1.z; v1.w += bv1.w;
-      if (p.res_s8 != nullptr) premvos::join_split8(r0[i], r1[i]);       // -> the eight floats hi + lo
-      if (has_res) {
-        v0.x += r0[i].x; v0.y += r0[i].y; v0.z += r0[i].z; v0.w += r0[i].w;
-        v1.x += r1[i].x; v1.y += r1[i].y; v1.z += r1[i].z; v1.w += r1[i].w;
-      }
-      v0.x = activate(v0.x); v0.y = activate(v0.y); v0.z = activate(v0.z); v0.w = activate(v0.w);
-      v1.x = activate(v1.x); v1.y = activate(v1.y); v1.z = activate(v1.z); v1.w = activate(v1.w);
-      if (m < p.M && col_ok) {
-        if (p.out != nullptr) {
-          float* o = p.out + m * p.out_ps + col;
-          *reinterpret_cast<float4*>(o) = v0;
-          *reinterpret_cast<float4*>(o + 4) = v1;
-        }
-        if (p.out_s8 != nullptr) premvos::store_split8(p.out_s8 + (m * p.out_s8_ps + col) * 4, v0, v1);
-      }
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  const int KT = p.kc32;
+  if (grp == 0) {
+    issue(0, 0);
+    if (KT > 1) {
+      issue(1, 1);
+      wait_vm(16);                                        // stage 0 has landed (stage 1 may still be in flight)
+    } else {
+      wait_vm(0);
     }
-    __builtin_amdgcn_wave_barrier();
+  } else {
+    asm volatile("s_barrier" ::: "memory");               // group 1 runs one phase behind
   }
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_barrier" ::: "memory");               // ---- load phase of this group (the other group multiplies)
+    frags(lds + (kt & 1) * STAGE);
+    if (grp == 0 && kt >= 1 && kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);     // (buffer (kt + 1) & 1: group 1 finished reading it a phase ago)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // ---- MFMA phase of this group (the other group loads)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      term(al[s_], bh[s_]);
+      term(ah[s_], bl[s_]);
+      term(ah[s_], bh[s_]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) wait_vm(0);                             // the next stage is in LDS before the barrier that opens its first reader's phase
+  }
+  if (grp == 0) asm volatile("s_barrier" ::: "memory");   // (the barrier group 1 spent ahead of the loop)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both groups are done with the operand buffers
+  epilogue<MI, NI>(p, acc, lds, wave, lane, m0 + grp * 128, n0 + wn * 64);
+}
+
+int launch_pp(const S8Args& a0, hipStream_t s) {
+  constexpr int LDS_BYTES = 2 * 512 * 128;
+  static const bool attr_done = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_s8_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    return true;
+  }();
+  (void)attr_done;
+  S8Args a = a0;
+  a.n_tiles = premvos::cdiv(a.cout, 256);
+  const long m_tiles = (a.M + 255) / 256;
+  hipLaunchKernelGGL(conv_bf16x3_s8_pp_kernel, dim3((unsigned)(m_tiles * a.n_tiles)), dim3(512), LDS_BYTES, s, a);
+  return premvos::check_launch("conv_bf16x3_s8 (ping-pong)");
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int KC = 32, int OCC = 1>
@@ -425,6 +574,12 @@ extern "C" int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* dp, const voi
     case 7: return launch<256, 128, 2, 2, 2, 16, 2>(a, s);   // 2 x 24 KB
     case 8: return launch<128, 256, 2, 2, 3, 16, 2>(a, s);   // the transposed wave tile (64 x 128 per wave)
     case 9: return launch<256, 64, 4, 1, 3, 32>(a, s);    // narrow layers (cout <= 64): four waves of 64 x 64, 3 x 40 KB
+    case 10: {                                            // ping-pong 256 x 256 (pointwise layers whose operands span < 4 GB each)
+      const bool pw = a.taps == 1 && a.sh == 1 && a.sw == 1 && a.pt == 0 && a.pl == 0 && a.h == a.ho && a.w == a.wo;
+      const bool small = a.M * (long)a.in_ps * 4 < (1L << 32) && (long)a.cout_pad * a.kc32 * 128 < (1L << 32);
+      const bool padded = a.cout_pad % 256 == 0;         // (ops.pack_conv_s8 pads the weight rows to whole 256-row tiles)
+      return pw && small && padded ? launch_pp(a, s) : launch<256, 256, 2, 4, 2>(a, s);
+    }
     default: return premvos::fail(PREMVOS_EINVAL, "conv_bf16x3_s8: unknown tile %d", tile);
   }
 }

@@ -670,7 +670,7 @@ def pack_conv_s8(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cud
     cout, cin, kh, kw = w.shape
     if scale is not None:
         w = w * scale.detach().to(torch.float32).cpu().view(-1, 1, 1, 1)
-    cout_pad, kc = _r(cout, 32), -(-cin // 32)
+    cout_pad, kc = _r(cout, 256), -(-cin // 32)          # (whole 256-row tiles: the ping-pong kernel addresses weight rows by a fixed stride)
     full = torch.zeros((cout_pad, kh * kw, kc * 32), dtype=torch.float32)
     full[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
     hi = full.to(torch.bfloat16)
@@ -717,14 +717,11 @@ S8_HINT = 6          # ConvDesc.tile_hint of a launch that goes to premvos_conv_
 
 
 def s8_tile_rule(m: int, cout: int) -> int:
-    """Tile of an S8 conv as a closed-form function of its shape (no timing: the same kernel on every rank and run): 256 x 256 /
-    eight waves where both dimensions fill it and the launch still has > 1.5 rounds of workgroups, 256 x 128 for narrower layers,
-    128 x 128 for small maps."""
-    if cout > 128 and -(-m // 256) * -(-cout // 256) >= 384:
-        return 0
-    if -(-m // 256) * -(-cout // 128) >= 256:
-        return 1
-    return 4
+    """Tile of an S8 conv as a closed-form function of its shape (no timing: the same kernel on every rank and run; every tile adds
+    the products in the same order, so the choice never changes a result).  From tools/dev/s8_bench.py on MI355X
+    (profiles/r04_s8_bench.txt): 256 x 256 / eight waves wherever the layer is wider than one 128-column tile; 128 x 128 with two
+    workgroups per CU (64 KB of LDS each: one's epilogue under the other's K loop) for cout <= 128."""
+    return 0 if cout > 128 else 5
 
 
 def conv_s8(x: NHWC, pk: PackedConvS8, out: Optional[NHWC] = None, out_s8: Optional[NHWC] = None, tile: Optional[int] = None,
