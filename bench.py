@@ -276,12 +276,13 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32"):
         st = [k for k in per_stage if k != "flow" or flow_prec != "fp32"]
         a16 = sum(fl[k] for k in st) / (sum(tm[k] for k in st) * 1e-3) / 1e12
         mult = 3.0 if net_prec == "bf16x3" else 1.0
-        return {"bound": "mfma", "kernel": f"conv_igemm_bf16_kernel<NPASS={int(mult)}> (fp32 activations split into bf16 hi(/lo) while staged, "
-                                           f"v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
-                                           + (" and, for the pointwise halves of the refinement net's separable convs, pwconv_bf16x3_split_kernel "
-                                              "(the depthwise half stores {hi, lo} bf16 groups in place of its floats; pure bf16 staging)"
-                                              if net_prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" else "")
-                                           + f" for the stages {st}; flow on the fp32 pipe: {flow_prec == 'fp32'}",
+        kern = ("conv_bf16x3_s8_kernel (implicit GEMM on activations RESIDENT in the split layout S8 = {hi8, lo8} bf16 per group of 8 channels, "
+                "staged by LDS-DMA, v_mfma_f32_32x32x16_bf16, three MFMAs per product, fp32 accumulate: the ResNet bottleneck chains of "
+                "groups 1-3 incl. their 3x3 layers, every K >= 256 pointwise conv of the refinement net); the HBM-bound short-K layers, "
+                "the RPN 3x3 (F(4x4,3x3)) and the stems stay on the fp32 kernels") if net_prec == "bf16x3" and \
+            os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0" else \
+            f"conv_igemm_bf16_kernel<NPASS={int(mult)}> (fp32 activations split into bf16 hi(/lo) while staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
+        return {"bound": "mfma", "kernel": kern + f" for the stages {st}; flow on the fp32 pipe: {flow_prec == 'fp32'}",
                 "achieved": round(a16, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a16 / PEAK_BF16_TFLOPS, 4),
                 "mfma_issue_frac": round(mult * a16 / PEAK_BF16_TFLOPS, 4), "traffic": None,
                 "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()},

@@ -37,13 +37,10 @@ extern "C" {
 #define PREMVOS_ACT_RELU 1
 #define PREMVOS_ACT_LEAKY 2 /* x > 0 ? x : slope * x   (nn.LeakyReLU(0.1), PWCNet.py:28) */
 #define PREMVOS_ACT_SIGMOID 3 /* 1/(1+exp(-x))   (mask head, proposal_net/train.py:305) */
-/* OR-ed into `act` of premvos_dwconv3x3_f32, and of premvos_conv2d_f32 for a layer run as Winograd F(4x4,3x3) (tile_hint 4):
- * store every group of four output channels as the 16 bytes {hi(4 x bf16), lo(4 x bf16)}, x = hi + lo (hi = bf16(x)
- * round-to-nearest-even, lo = bf16(x - hi)), in place of the four floats -- the input form of premvos_pwconv_bf16x3_split_f32 */
-#define PREMVOS_ACT_SPLIT_BF16 0x100
-/* Round 4, same producers: store the result in the resident split layout "S8" instead -- every group of EIGHT channels of a pixel
- * is the 32 bytes {hi(8 x bf16), lo(8 x bf16)} (pixel stride a multiple of 8 floats' worth, channel window 32-byte aligned) -- the
- * operand form of premvos_conv_bf16x3_s8_f32. */
+/* OR-ed into `act` of premvos_dwconv3x3_f32: store the result in the resident split layout "S8" of the bf16x3 mode -- every group
+ * of EIGHT channels of a pixel is the 32 bytes {hi(8 x bf16), lo(8 x bf16)}, x = hi + lo (hi = bf16(x) round-to-nearest-even,
+ * lo = bf16(x - hi)), in place of its eight floats (pixel stride a multiple of 8 floats' worth, channel window 32-byte aligned)
+ * -- the operand form of premvos_conv_bf16x3_s8_f32.  (Round 3's {hi4, lo4} groups, 0x100, and their consumer are gone.) */
 #define PREMVOS_ACT_SPLIT8_BF16 0x200
 
 /* arithmetic of the dense-conv MFMA pipe (activations and outputs are fp32 in HBM in every mode) */
@@ -258,19 +255,6 @@ int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, int32_t h, 
                           const float* wgt, const float* bias, int32_t c_pad, float* out, int32_t out_ps, int32_t ho,
                           int32_t wo, int32_t stride, int32_t dilation, int32_t pt, int32_t pl, int32_t pre_relu,
                           int32_t act, void* stream);
-
-/* The pointwise half of a separable conv (slim.separable_conv2d, core/xception.py:154-178; model.py:664-707) on the bf16 matrix
- * pipe with fp32-class accuracy (a*b ~= hi(a)hi(b) + hi(a)lo(b) + lo(a)hi(b), fp32 accumulate: the optional "bf16x3" mode), for
- * an input that its producer already split: in_split is what premvos_dwconv3x3_f32 wrote with PREMVOS_ACT_SPLIT_BF16 -- [m]
- * pixels of in_ps floats' worth of bytes, every 16 bytes = {hi, lo} of four channels.  wgt_hi / wgt_lo: bf16 [cout_pad][k_pad]
- * (k = input channel, k_pad % 32 == 0, zero padded; hi = bf16(w), lo = bf16(w - hi), frozen BatchNorm folded in).
- * out[m][cout] (fp32, pixel stride out_ps) = act(sum + bias (+ res)); act: NONE / RELU / LEAKY.  out_split (optional, pixel
- * stride out_split_ps floats' worth of bytes): the same values once more as {hi, lo} groups, for the next pointwise layer of a
- * residual chain whose fp32 `out` is still needed (bottleneck conv3 -> next conv1 + shortcut, basemodel.py:49-59). */
-int premvos_pwconv_bf16x3_split_f32(const void* in_split, int32_t in_ps, int64_t m, int32_t cin, const void* wgt_hi,
-                                    const void* wgt_lo, int32_t k_pad, int32_t cout, int32_t cout_pad, const float* bias,
-                                    const float* res, int32_t res_ps, float* out, int32_t out_ps, void* out_split,
-                                    int32_t out_split_ps, int32_t act, float slope, void* stream);
 
 /* Round 4: the bf16x3 mode on activations RESIDENT in the split layout "S8" -- per pixel, every group of 8 channels is the 32 bytes
  * {hi(8 x bf16), lo(8 x bf16)} (x = hi + lo; 4 bytes per element like fp32, pixel stride a multiple of 8 floats' worth of bytes,

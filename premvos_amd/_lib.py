@@ -14,11 +14,10 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 11         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
+ABI_VERSION = 12         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
-ACT_SPLIT_BF16 = 0x100       # premvos_dwconv3x3_f32 / F(4x4) conv: emit {hi, lo} bf16 groups for premvos_pwconv_bf16x3_split_f32
-ACT_SPLIT8_BF16 = 0x200      # same producers: the resident S8 layout ({hi8, lo8} per group of 8 channels) for premvos_conv_bf16x3_s8_f32
+ACT_SPLIT8_BF16 = 0x200      # premvos_dwconv3x3_f32: store the resident S8 layout ({hi8, lo8} per group of 8 channels) for premvos_conv_bf16x3_s8_f32
 OUT_NHWC, OUT_PIXSHUF2 = 0, 1
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
@@ -67,8 +66,6 @@ SIGNATURES = {
     "premvos_refine_input_u8": [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "premvos_dwconv3x3_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32,
                               _i32, _i32, _i32, _i32, _vp],
-    "premvos_pwconv_bf16x3_split_f32": [_vp, _i32, C.c_int64, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
-                                        _i32, _f32, _vp],
     "premvos_conv_bf16x3_s8_f32": [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp],
     "premvos_split8_f32": [_vp, _i32, _vp, _i32, C.c_int64, _i32, _vp],
     "premvos_resize_bilinear_f32": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -56,17 +56,6 @@ __device__ inline int xcd_contiguous(int id, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-// PREMVOS_ACT_SPLIT_BF16: four fp32 channels -> the 16 bytes {hi(4 x bf16), lo(4 x bf16)}, x = hi + lo with hi = bf16(x) (round
-// to nearest even) and lo = bf16(x - hi); stored in place of the four floats by the producers that feed
-// premvos_pwconv_bf16x3_split_f32 (csrc/pwconv_bf16x3_split.hip), which then stages pure bf16.
-__device__ __forceinline__ float4 split_bf16_group(const float4 r) {
-  using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
-  const bf16x4 hi = {(__bf16)r.x, (__bf16)r.y, (__bf16)r.z, (__bf16)r.w};
-  const bf16x4 lo = {(__bf16)(r.x - (float)hi[0]), (__bf16)(r.y - (float)hi[1]), (__bf16)(r.z - (float)hi[2]), (__bf16)(r.w - (float)hi[3])};
-  const uint2 h = __builtin_bit_cast(uint2, hi), l = __builtin_bit_cast(uint2, lo);
-  return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
-}
-
 // The resident split layout "S8" (round 4, csrc/conv_bf16x3_s8.hip): every group of EIGHT channels of a pixel is the 32 bytes
 // {hi(8 x bf16), lo(8 x bf16)} -- a 16-byte half is exactly one operand of v_mfma_f32_32x32x16_bf16, so the consumer stages it by
 // LDS-DMA and reads fragments with one ds_read_b128, no re-pairing.  x = hi + lo, hi = bf16(x) (round to nearest even), lo = bf16(x - hi).

@@ -1,8 +1,8 @@
 // Convolution (1x1 and k x k, any stride / dilation / padding) as an implicit GEMM on the gfx950 bf16 matrix pipe with fp32-class
 // accuracy ("bf16x3": a*b ~= hi(a)hi(b) + hi(a)lo(b) + lo(a)hi(b), fp32 accumulate) on activations that are RESIDENT in HBM in the
 // split layout "S8": per pixel, every group of 8 channels is the 32 bytes {hi(8 x bf16), lo(8 x bf16)} -- 4 bytes per element like
-// fp32, same pixel stride, written once by the producing kernel (this kernel's own epilogue, premvos_dwconv3x3_f32 / the F(4x4,3x3)
-// output transform with PREMVOS_ACT_SPLIT_BF16, premvos_split8_f32).  Round 4: the round-3 split kernel
+// fp32, same pixel stride, written once by the producing kernel (this kernel's own epilogue, premvos_dwconv3x3_f32 with
+// PREMVOS_ACT_SPLIT8_BF16, premvos_split8_f32).  Round 4: the round-3 split kernel
 // (128 x 128 tile, register staging + ds_write_b128, {hi4, lo4} groups re-paired in registers) sat at 0.29 of the bf16 pipe because
 // a stage's LDS traffic -- 16 KB of ds_write_b128 at ~79 B/clk plus the fragment reads -- took as many cycles as its MFMAs.  Here:
 //

@@ -864,10 +864,8 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   PV_REQUIRE(d.out_ps >= (d.out_mode == PREMVOS_OUT_PIXSHUF2 ? d.cout_ps : d.cout), "conv2d: out_ps < cout");
   PV_REQUIRE(d.res == nullptr || d.res_ps >= d.cout, "conv2d: res_ps < cout");
   PV_REQUIRE(d.res == nullptr || d.out_mode == PREMVOS_OUT_NHWC, "conv2d: residual needs NHWC output");
-  PV_REQUIRE((d.act & ~PREMVOS_ACT_SPLIT_BF16) >= PREMVOS_ACT_NONE && (d.act & ~PREMVOS_ACT_SPLIT_BF16) <= PREMVOS_ACT_SIGMOID,
+  PV_REQUIRE(d.act >= PREMVOS_ACT_NONE && d.act <= PREMVOS_ACT_SIGMOID,
              "conv2d: bad activation");
-  PV_REQUIRE(!(d.act & PREMVOS_ACT_SPLIT_BF16) || (d.tile_hint == 4 && d.precision == PREMVOS_PREC_F32),
-             "conv2d: PREMVOS_ACT_SPLIT_BF16 (split bf16 output) is implemented by the F(4x4,3x3) output transform only (tile_hint 4)");
   if (d.out_mode == PREMVOS_OUT_PIXSHUF2)
     PV_REQUIRE(d.cout_ps > 0 && d.cout == 4 * d.cout_ps, "conv2d: PIXSHUF2 needs cout == 4*cout_ps");
   else
@@ -982,4 +980,4 @@ extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* 
   return premvos::check_launch("mfma_f32_calibrate");
 }
 
-extern "C" int premvos_abi_version(void) { return 11; }   // bump with every change of include/premvos_hip.h
+extern "C" int premvos_abi_version(void) { return 12; }   // bump with every change of include/premvos_hip.h

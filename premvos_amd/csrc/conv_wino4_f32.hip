@@ -324,8 +324,8 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const premvos_conv_de
           v = make_float4(1.f / (1.f + expf(-v.x)), 1.f / (1.f + expf(-v.y)), 1.f / (1.f + expf(-v.z)), 1.f / (1.f + expf(-v.w)));
         }
         float* o = p.out + pix * p.out_ps + col;
-        if constexpr (WIDE) {      // PREMVOS_ACT_SPLIT_BF16: {hi, lo} bf16 groups for premvos_pwconv_bf16x3_split_f32 (wide stores only)
-          *reinterpret_cast<float4*>(o) = (p.act & PREMVOS_ACT_SPLIT_BF16) ? premvos::split_bf16_group(v) : v;
+        if constexpr (WIDE) {
+          *reinterpret_cast<float4*>(o) = v;
         } else {
           o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         }
@@ -414,8 +414,6 @@ int conv_wino4(const premvos_conv_desc& d, hipStream_t s) {
   const int grid = (int)(total / 256 > (1 << 20) ? (1 << 20) : (total + 255) / 256);
   const bool wide = (d.out_ps & 3) == 0 && aligned16(d.out) && (d.res == nullptr || ((d.res_ps & 3) == 0 && aligned16(d.res))) &&
                     (d.bias == nullptr || aligned16(d.bias));
-  if (!wide && (d.act & PREMVOS_ACT_SPLIT_BF16))
-    return fail(PREMVOS_EINVAL, "conv2d: PREMVOS_ACT_SPLIT_BF16 needs 16-byte aligned output pixels (out_ps %% 4 == 0)");
   if (wide) {
     hipLaunchKernelGGL(wino4_output_kernel<true>, dim3(grid), dim3(256), 0, s, d, Ms, g.ty, g.tx, g.n_tiles * g.bn);
   } else {

@@ -82,13 +82,11 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const uint8_t* __rest
   }
 }
 
-// PREMVOS_ACT_SPLIT_BF16 (bit 8 of `act`): the depthwise result of four channels is stored split (common.h: split_bf16_group)
-__device__ __forceinline__ float4 split_or_plain(const float4 r, const bool split) { return split ? premvos::split_bf16_group(r) : r; }
-// The store of one (pixel, 4-channel unit) result: floats, the {hi4, lo4} group of round 3, or -- PREMVOS_ACT_SPLIT8_BF16 (bit 9) -- half
-// of a group of the resident S8 layout (common.h: store_split4; csrc/conv_bf16x3_s8.hip reads it by LDS-DMA)
+// The store of one (pixel, 4-channel unit) result: floats, or -- PREMVOS_ACT_SPLIT8_BF16 (bit 9 of `act`) -- half of a group of the
+// resident S8 layout of the bf16x3 mode (common.h: store_split4; csrc/conv_bf16x3_s8.hip reads it by LDS-DMA)
 __device__ __forceinline__ void store_unit(float* pixel, const int cg, const float4 r, const int act) {
   if (act & PREMVOS_ACT_SPLIT8_BF16) premvos::store_split4(reinterpret_cast<char*>(pixel), cg, r);
-  else *reinterpret_cast<float4*>(pixel + cg * 4) = split_or_plain(r, (act & PREMVOS_ACT_SPLIT_BF16) != 0);
+  else *reinterpret_cast<float4*>(pixel + cg * 4) = r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -476,9 +474,7 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
                  (bias == nullptr || premvos::aligned16(bias)),
              "dwconv3x3: pointers must be 16-byte aligned");
   PV_REQUIRE((act & 0xff) == PREMVOS_ACT_NONE || (act & 0xff) == PREMVOS_ACT_RELU, "dwconv3x3: bad activation");
-  PV_REQUIRE((act & ~0xff & ~PREMVOS_ACT_SPLIT_BF16 & ~PREMVOS_ACT_SPLIT8_BF16) == 0 &&
-                 (act & (PREMVOS_ACT_SPLIT_BF16 | PREMVOS_ACT_SPLIT8_BF16)) != (PREMVOS_ACT_SPLIT_BF16 | PREMVOS_ACT_SPLIT8_BF16),
-             "dwconv3x3: unknown output-layout flags");
+  PV_REQUIRE((act & ~0xff & ~PREMVOS_ACT_SPLIT8_BF16) == 0, "dwconv3x3: unknown output-layout flags");
   PV_REQUIRE(!(act & PREMVOS_ACT_SPLIT8_BF16) || (out_ps % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31u) == 0),
              "dwconv3x3: an S8 output needs out_ps %% 8 == 0 and a 32-byte aligned channel window");
   hipStream_t s = static_cast<hipStream_t>(stream);

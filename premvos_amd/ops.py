@@ -122,8 +122,6 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
     hi = full.to(torch.bfloat16)
     if prec != _lib.PREC_BF16X3:
         return PackedConv(hi.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec, None)
-    # hi and lo matrices in ONE allocation, lo right behind hi: premvos_pwconv_bf16x3_split_f32 addresses both with 32-bit offsets
-    # from one base
     both = torch.stack([hi, (full - hi.float()).to(torch.bfloat16)]).to(device).contiguous()
     return PackedConv(both[0], b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec, both[1])
 
@@ -721,6 +719,9 @@ def s8_tile_rule(m: int, cout: int) -> int:
     the products in the same order, so the choice never changes a result).  From tools/dev/s8_bench.py on MI355X
     (profiles/r04_s8_bench.txt): 256 x 256 / eight waves wherever the layer is wider than one 128-column tile; 128 x 128 with two
     workgroups per CU (64 KB of LDS each: one's epilogue under the other's K loop) for cout <= 128."""
+    forced = os.environ.get("PREMVOS_S8_TILE")               # developer A/B runs only
+    if forced:
+        return int(forced)
     return 0 if cout > 128 else 5
 
 
@@ -753,20 +754,6 @@ def conv2d(x: NHWC, pk: PackedConv, out: NHWC, **kw):
     d = conv_desc(x, pk, out, **kw)
     ws = assign_workspace([d], x.buf.device)          # noqa: F841  (kept alive until the launch is enqueued)
     _lib.check(_lib.load().premvos_conv2d_f32(C.byref(d), _lib.current_stream()), "conv2d")
-    return out
-
-
-def pwconv_bf16x3_split(x: NHWC, pk: PackedConv, out: NHWC, act=ACT_NONE, slope=0.1, res: Optional[NHWC] = None,
-                        out_split: Optional[NHWC] = None):
-    """Pointwise conv of an input whose producer stored it split into bf16 hi / lo (premvos_dwconv3x3_f32 / an F(4x4) conv with
-    ACT_SPLIT_BF16, or this op's own ``out_split``); ``pk`` packed with precision="bf16x3" (bf16 hi / lo matrices)."""
-    assert pk.precision == _lib.PREC_BF16X3 and pk.wgt_lo is not None and (pk.kh, pk.kw) == (1, 1) and x.c == pk.cin
-    assert (x.n, x.h, x.w) == (out.n, out.h, out.w) and out.c == pk.cout
-    _lib.check(_lib.load().premvos_pwconv_bf16x3_split_f32(
-        x.ptr, x.ps, x.n * x.h * x.w, x.c, pk.wgt.data_ptr(), pk.wgt_lo.data_ptr(), pk.k_pad, pk.cout, pk.cout_pad,
-        pk.bias.data_ptr() if pk.bias is not None else None, res.ptr if res is not None else None,
-        res.ps if res is not None else 0, out.ptr, out.ps, out_split.ptr if out_split is not None else None,
-        out_split.ps if out_split is not None else 0, act, slope, _lib.current_stream()), "pwconv_bf16x3_split")
     return out
 
 

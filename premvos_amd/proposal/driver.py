@@ -110,21 +110,26 @@ class ProposalStage:
         second-head outputs too, seven small synchronous copies per image)."""
         assert not self.net.mode_mask
         p = self.plan
-        counts = p.final_count.cpu().numpy()
-        boxes, probs = p.final_boxes.cpu().numpy(), p.final_probs.cpu().numpy()
-        out = []
-        for i in range(self.batch):
-            n = int(counts[i])
-            none = [None] * n
-            res = _to_results(boxes[i, :n].copy(), probs[i, :n].copy(), np.ones((n,), np.int64), none, none, none, self.scale,
-                              orig_hw)
-            out.append(convert_results_to_json(res))
-        return out
+        return results_json(p.final_boxes.cpu().numpy(), p.final_probs.cpu().numpy(), p.final_count.cpu().numpy(), self.scale, orig_hw)
 
     def detections(self, i: int, orig_hw) -> List[SecondDetectionResult]:
         boxes, probs, labels, post, sl, sp, _ = self.net.outputs(self.plan, i)
         masks = self.net.masks(self.plan, i) if self.net.mode_mask else None
         return _to_results(boxes, probs, labels, post, sl, sp, self.scale, orig_hw, masks)
+
+
+def results_json(boxes: np.ndarray, probs: np.ndarray, counts: np.ndarray, scale: float, orig_hw) -> List[List[dict]]:
+    """The proposal JSON of a batch from the net's output arrays (``final_boxes`` [B,20,4] in RESIZED-image coordinates,
+    ``final_probs`` [B,20], ``final_count`` [B]): un-scale, clip (eval.py:93-94), xywh / rounding (train.py:388-428).  A pure
+    function of the arrays, so the merge rank of a gathered job writes the bytes the producing rank would have written."""
+    out = []
+    for i in range(len(counts)):
+        n = int(counts[i])
+        none = [None] * n
+        res = _to_results(np.array(boxes[i, :n], dtype=np.float32), np.array(probs[i, :n], dtype=np.float32), np.ones((n,), np.int64), none, none,
+                          none, scale, orig_hw)
+        out.append(convert_results_to_json(res))
+    return out
 
 
 def _cv_resize_f32(img: np.ndarray, dst_w: int, dst_h: int) -> np.ndarray:

@@ -231,6 +231,37 @@ class RefinementEngine:
         finish()
         return proposal_lists
 
+    def refine_frames_device(self, images, proposal_lists, out_masks: torch.Tensor, out_conf: torch.Tensor, lane: int = 0) -> None:
+        """``refine_frames`` for a caller that keeps the results in HBM (premvos_amd.stream --gather): the masks of frame j's n_j
+        proposals go to ``out_masks[j, :n_j, :H, :W]`` (uint8, a block at least as large as the frame), their conf to
+        ``out_conf[j, :n_j]``; nothing crosses PCIe, no RLE string is built.  Same packed launches as ``refine_frames``."""
+        live = [(j, im, pr) for j, (im, pr) in enumerate(zip(images, proposal_lists)) if pr]
+        if not live:
+            return
+        H, W = live[0][1].shape[:2]
+        if len(live) == 1 or max(len(pr) for _, _, pr in live) > self.max_boxes:
+            for j, im, pr in live:
+                boxes = _boxes_from_proposals(pr)
+                frame = jpeg.to_device(im, self.net.device)
+                for s0 in range(0, len(pr), self.max_boxes):
+                    chunk = boxes[s0:s0 + self.max_boxes]
+                    P = self.max_boxes if len(pr) > self.max_boxes else _bucket(len(chunk))
+                    p = self.net.refine(frame, torch.from_numpy(chunk).to(self.net.device), max_boxes=P, lane=lane)
+                    out_masks[j, s0:s0 + len(chunk), :H, :W].copy_(p.mask[:len(chunk)])
+                    out_conf[j, s0:s0 + len(chunk)].copy_(p.conf[:len(chunk)])
+            return
+        total = sum(len(pr) for _, _, pr in live)
+        boxes = [_boxes_from_proposals(pr) for _, _, pr in live]
+        frames = jpeg.stack_frames([im for _, im, _ in live], self.net.device)
+        group = max(len(live), int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
+        p = self.net.refine_packed(frames, [torch.from_numpy(b) for b in boxes], _bucket_total(total), group, lane=lane)
+        off = 0
+        for j, _, pr in live:                       # the slots of a frame are contiguous
+            n = len(pr)
+            out_masks[j, :n, :H, :W].copy_(p.mask_g[0, off:off + n])
+            out_conf[j, :n].copy_(p.conf_g[0, off:off + n])
+            off += n
+
     def refine_boxes(self, frame_u8: np.ndarray, boxes_y0x0y1x1: np.ndarray):
         """-> (mask uint8 [n,H,W], posterior f32 [n,H,W], conf f32 [n]) as numpy."""
         n = len(boxes_y0x0y1x1)

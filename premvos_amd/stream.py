@@ -88,26 +88,35 @@ class StreamPipeline:
         self.flow_stages, self.prop_stages = {}, {}
 
     # ---- the stage bodies (each runs on its own host thread and HIP stream) ----------------------------------------
-    def _flow(self, chunk, writer):                 # chunk: (seq, names, frames [n,H,W,3] uint8 RGB, next frame or None)
+    def _flow(self, chunk, writer):                 # chunk: (seq, names, frames [n,H,W,3] uint8 RGB, next frame or None, staging)
         from .flow.driver import FlowStage
-        seq, names, frames, nxt = chunk
+        seq, names, frames, nxt, stg = chunk
         second = list(frames[1:]) + ([nxt] if nxt is not None else [])
         n = len(second)                             # pairs in this chunk (the last frame of a video has none)
         if n == 0:
+            if stg is not None:
+                stg["_done"]("flow")
             return None
         with torch.cuda.stream(self.streams["flow"]):
             if n not in self.flow_stages:
                 self.flow_stages[n] = FlowStage(net=self.flow_net, batch=n, use_graph=False)
             im1 = jpeg.stack_frames(frames[:n], self.dev)
             im2 = jpeg.stack_frames(second, self.dev)
-            flo = self.flow_stages[n].run(im1, im2).cpu().numpy()
+            res = self.flow_stages[n].run(im1, im2)
+            if stg is not None:                     # --gather: the result stays in HBM, in the chunk's staging block
+                h, w = res.shape[1:3]
+                stg["flow"][:n, :h, :w].copy_(res)
+                self.streams["flow"].synchronize()
+                stg["_done"]("flow")
+                return None
+            flo = res.cpu().numpy()
         for k in range(n):           # (the directory is made by whoever WRITES the file: with --gather that is the merge rank only)
             writer.submit(_write_flo, os.path.join(self.out, "flow", seq, names[k] + ".flo"), flo[k])
         return None
 
     def _proposals(self, which, chunk, writer):
         from .proposal import driver as pd
-        seq, names, frames, _ = chunk
+        seq, names, frames, _, stg = chunk
         n, orig, net = len(frames), frames[0].shape[:2], self.nets[which]
         with torch.cuda.stream(self.streams[f"prop{which}"]):
             key = (which, n)
@@ -115,14 +124,32 @@ class StreamPipeline:
                 self.prop_stages[key] = pd.ProposalStage({}, batch=n, device=net.device, net=net, rgb_input=True, use_graph=False)
             st = self.prop_stages[key]
             st.run(jpeg.stack_frames(frames, self.dev))
-            lists = st.json_results(orig)
+            if stg is not None:                     # --gather: the detections go to the merge rank as the arrays they are
+                tag, pl = ("general", "specific")[which], st.plan
+                stg[tag + "_boxes"][:n].copy_(pl.final_boxes)
+                stg[tag + "_probs"][:n].copy_(pl.final_probs)
+                stg[tag + "_count"][:n].copy_(pl.final_count)
+            lists = st.json_results(orig)           # (the refinement stage of THIS rank needs the rounded boxes; this also synchronises)
+        if stg is not None:
+            stg["_done"](("general", "specific")[which])
+            return chunk, lists
         sub = ("general_proposals", "specific_proposals")[which]
         for k in range(n):
             writer.submit(_dump_json, os.path.join(self.out, sub, seq, names[k] + ".json"), lists[k])
         return chunk, lists
 
     def _refine(self, item, writer, lane: int = 0):
-        (seq, names, frames, _), general, specific = item
+        (seq, names, frames, _, stg), general, specific = item
+        if stg is not None:                           # --gather: masks + conf stay in HBM; the merge rank builds every JSON
+            st = self.streams[f"ref{lane}"]
+            with torch.cuda.stream(st):
+                G = max(1, int(os.environ.get("PREMVOS_DRIVER_BATCH", "4")))
+                for s0 in range(0, len(frames), G):
+                    boxes = [[dict(p) for p in general[k] + specific[k]] for k in range(s0, min(s0 + G, len(frames)))]
+                    self.engine.refine_frames_device(frames[s0:s0 + G], boxes, stg["masks"][s0:s0 + G], stg["conf"][s0:s0 + G], lane=lane)
+                st.synchronize()
+            stg["_done"]("refine")
+            return None
         combined = []
         for k in range(len(frames)):
             both = general[k] + specific[k]           # combine_general_and_specific.py:33
@@ -153,13 +180,64 @@ class StreamPipeline:
                 writer.submit(_dump_json, fn, props)
         return None
 
+    def _decode_round(self, gather: "DeviceGather", prev, writer):
+        """Merge rank: wait for the gather of round ``prev`` and turn every rank's buffer into files (other ranks: just wait)."""
+        k, slot = prev
+        gather.x.wait(slot)
+        if gather.rank != gather.x.dst:
+            return
+        bufs = gather.x.gathered_slot(slot)
+        for r in range(gather.world):
+            if k < len(gather.chunks[r]):
+                gather.decode_and_write(r, k, bufs[r], self.out, writer)
+
     # ---- the driver ---------------------------------------------------------------------------------------------------
-    def run_sequences(self, folders: List[str], shards: Optional[List[tuple]] = None, writer=None) -> int:
+    def run_sequences(self, folders: List[str], shards: Optional[List[tuple]] = None, writer=None, gather: "Optional[DeviceGather]" = None) -> int:
         """``shards``: (index into folders, first frame, end frame) items (premvos_amd.parallel.plan_shards); None = every
-        frame of every folder.  Returns the number of frames this process owned."""
+        frame of every folder.  ``gather``: hand the results to the merge rank (``DeviceGather``) instead of writing them.
+        Returns the number of frames this process owned."""
         errors: List[BaseException] = []
         own_writer = writer is None
         writer = iop.Writer(enabled=True) if own_writer else writer
+        ready: "queue.Queue" = queue.Queue()          # --gather: chunks whose four parts are in their staging block, as they complete
+        free_stg: "queue.Queue" = queue.Queue()
+        xthread = None
+        if gather is not None:
+            for _ in range(4):                        # staging blocks in flight: decode-ahead + the stages + the exchange
+                free_stg.put(gather.staging())
+
+            def exchange_loop():
+                """ONE thread issues the collectives, in chunk order: round k = this rank's k-th chunk (a filler when it has none);
+                the gather of round k is in flight while round k + 1 is computed / packed; the merge rank decodes round k - 1."""
+                try:
+                    x, pending, held = gather.x, {}, None
+                    filler = gather.staging()
+                    prev = None                        # (round, slot) whose gather was issued last
+                    for k in range(gather.rounds):
+                        if k < len(gather.chunks[gather.rank]):
+                            while k not in pending:
+                                idx, st_ = ready.get()
+                                if idx is None:
+                                    raise RuntimeError("a stage failed before its chunk was complete")
+                                pending[idx] = st_
+                            cur = pending.pop(k)
+                        else:
+                            cur = filler
+                        slot = x.exchange_async(cur)   # pack (device) + the one gather of this round, not waited for
+                        if cur is not filler:          # (packed: the staging block can take the next chunk)
+                            for key in ("flow", "masks"):
+                                cur[key].zero_()
+                            torch.cuda.current_stream().synchronize()      # packed and cleared before a stage stream writes it again
+                            free_stg.put(cur)
+                        if prev is not None:
+                            self._decode_round(gather, prev, writer)
+                        prev = (k, slot)
+                    if prev is not None:
+                        self._decode_round(gather, prev, writer)
+                except BaseException as e:             # noqa: BLE001
+                    errors.append(e)
+            xthread = threading.Thread(target=exchange_loop, name="premvos-exchange", daemon=True)
+            xthread.start()
         q_flow, q_g, q_s, q_rg, q_rs = (queue.Queue(maxsize=3) for _ in range(5))
         q_join: "queue.Queue" = queue.Queue(maxsize=3 + self.refine_lanes)
 
@@ -183,7 +261,7 @@ class StreamPipeline:
                    _stage_thread("prop-specific", lambda c: self._proposals(1, c, writer), q_s, q_rs, errors)]
         threads += [_stage_thread(f"refine{i}", lambda it, i=i: self._refine(it, writer, i), q_join, None, errors)
                     for i in range(self.refine_lanes)] + [joiner]
-        n_frames = 0
+        n_frames = n_chunks = 0
         if shards is None:
             shards = [(v, 0, None) for v in range(len(folders))]
 
@@ -207,10 +285,23 @@ class StreamPipeline:
                 for names, frames, nxt in iter_chunks(images, first, end, self.batch, jpeg.loader("1"), finish):
                     if errors:
                         break
-                    item = (seq, names, frames, nxt)
+                    stg = None
+                    if gather is not None:
+                        stg = free_stg.get()
+                        left, lock, idx = {"flow", "general", "specific", "refine"}, threading.Lock(), n_chunks
+
+                        def done(part, stg=stg, left=left, lock=lock, idx=idx):
+                            with lock:
+                                left.discard(part)
+                                last = not left
+                            if last:
+                                ready.put((idx, stg))
+                        stg["_done"] = done
+                    item = (seq, names, frames, nxt, stg)
                     for q in (q_flow, q_g, q_s):
                         q.put(item)
                     n_frames += len(frames)
+                    n_chunks += 1
                 if errors:
                     break
         except BaseException as e:                   # a decode / upload error on this thread: the stage threads must still end
@@ -220,6 +311,10 @@ class StreamPipeline:
                 q.put(_END)
             for t in threads:
                 t.join()
+            if xthread is not None:
+                if errors:
+                    ready.put((None, None))          # wake the exchange thread: it fails its round instead of waiting for ever
+                xthread.join()
             if own_writer:
                 try:
                     writer.close()
@@ -293,69 +388,108 @@ def _write_bytes(fn, data: bytes):
         f.write(data)
 
 
-class GatherWriter:
-    """``--gather``: instead of writing its files, a rank keeps (path, bytes) and hands them to the merge rank -- the rank that
-    will run the CPU-side MergeTrack -- in ONE padded gather per shard item (premvos_amd.parallel.gather_padded; RCCL over
-    xGMI on GPUs, gloo in the CPU tests); the merge rank writes every rank's files.  Same bytes as the per-rank writers: the
-    payloads are produced by the same functions (flo_bytes / json.dumps)."""
+def list_chunks(images: List[str], first: int, end: Optional[int], batch: int) -> List[tuple]:
+    """GPU- and decode-free twin of ``iter_chunks`` for a video whose frames all have one size (what ``--gather`` requires): the
+    chunks of frames [first, end) as (names, has_next) -- every rank computes every rank's list from the shard plan alone, so
+    the merge rank knows which frames a gathered buffer holds without any side channel."""
+    n = len(images)
+    end = n if end is None else min(end, n)
+    out = []
+    for c0 in range(first, end, batch):
+        c1 = min(c0 + batch, end)
+        out.append(([os.path.splitext(os.path.basename(fn))[0] for fn in images[c0:c1]], c1 < n))
+    return out
 
-    runs_callables = False                       # payloads must be (path, bytes): no deferred host work on this writer
 
-    def __init__(self, device, dst: int = 0):
-        self.files: List[tuple] = []
-        self.device, self.dst = device, dst
-        self._lock = threading.Lock()
+class DeviceGather:
+    """``--gather`` (north_star: "a single RCCL gather over xGMI to collect masks for the CPU-side merge"): a rank writes NO files.
+    Per chunk its results stay in HBM -- flow [n,H,W,2], the detections of both proposal nets, the refined masks [n,40,H,W] and
+    conf -- are packed on the device into ONE fixed-size buffer (premvos_amd.parallel.ResultExchange: masks bit-packed) and go to
+    the merge rank in ONE asynchronous gather per round of chunks (double-buffered: the collective of round k runs while round
+    k + 1 computes; ranks that own no chunk in a round send a filler).  The merge rank -- the one that will run MergeTrack --
+    decodes every rank's buffer (bit-unpack + RLE boundaries on ITS GPU, strings on its writer thread) and writes the files: the
+    same bytes the per-rank writers produce, because proposal JSON, conf strings and RLE are pure functions of the gathered
+    arrays (tests/test_gpu_plumbing.py compares the trees).  Round 3 gathered host-packed file bytes per shard item instead."""
 
-    def submit(self, fn, path, obj):
-        from .flow.driver import flo_bytes
-        data = flo_bytes(obj) if fn is _write_flo else json.dumps(obj).encode() if fn is _dump_json else None
-        if data is None:
-            raise TypeError(f"GatherWriter cannot serialise the payload of {fn}")
-        with self._lock:
-            self.files.append((path, data))
+    P = 40                       # combined proposals per frame: 20 general + 20 specific (config.py:123)
 
-    @staticmethod
-    def pack(files) -> bytes:
-        import struct
-        parts = [struct.pack("<I", len(files))]
-        for path, data in files:
-            pb = path.encode()
-            parts += [struct.pack("<IQ", len(pb), len(data)), pb, data]
-        return b"".join(parts)
+    def __init__(self, pipe: "StreamPipeline", folders: List[str], plans: List[List[tuple]], rank: int, world: int, device,
+                 pack_bits=None, unpack_bits=None):
+        from PIL import Image
+        from .parallel import ResultExchange
+        self.pipe, self.rank, self.world = pipe, rank, world
+        self.chunks: List[List[tuple]] = []          # per rank: (seq, names, has_next, (H, W))
+        sizes = {}
+        for r in range(world):
+            mine = []
+            for v, first, end in plans[r]:
+                images = sorted(glob.glob(os.path.join(folders[v], "*")))
+                if v not in sizes:
+                    with Image.open(images[0]) as im:
+                        sizes[v] = (im.size[1], im.size[0])
+                seq = folders[v].rstrip("/").split("/")[-1]
+                mine += [(seq, names, nxt, sizes[v]) for names, nxt in list_chunks(images, first, end, pipe.batch)]
+            self.chunks.append(mine)
+        self.rounds = max([len(c) for c in self.chunks] + [0])
+        hm = max([hw[0] for hw in sizes.values()] + [8])
+        wm = max([hw[1] for hw in sizes.values()] + [8])
+        self.hm, self.wm = hm, wm
+        self.x = ResultExchange(pipe.batch, hm, wm, self.P, device, pack_bits=pack_bits, unpack_bits=unpack_bits)
+        self.device = torch.device(device)
 
-    @staticmethod
-    def unpack(buf: bytes):
-        import struct
-        (n,), off, out = struct.unpack_from("<I", buf, 0), 4, []
-        for _ in range(n):
-            pl, dl = struct.unpack_from("<IQ", buf, off)
-            off += 12
-            out.append((buf[off:off + pl].decode(), bytes(buf[off + pl:off + pl + dl])))
-            off += pl + dl
-        return out
+    def staging(self) -> dict:
+        """The ``r`` dict of one chunk (ResultExchange.pack's input), zero-filled, at the job's largest frame size."""
+        B, dev = self.pipe.batch, self.device
+        return {"flow": torch.zeros((B, self.hm, self.wm, 2), dtype=torch.float32, device=dev),
+                "masks": torch.zeros((B, self.P, self.hm, self.wm), dtype=torch.uint8, device=dev),
+                "conf": torch.zeros((B, self.P), dtype=torch.float32, device=dev),
+                "general_boxes": torch.zeros((B, 20, 4), dtype=torch.float32, device=dev),
+                "general_probs": torch.zeros((B, 20), dtype=torch.float32, device=dev),
+                "general_count": torch.zeros((B,), dtype=torch.int32, device=dev),
+                "specific_boxes": torch.zeros((B, 20, 4), dtype=torch.float32, device=dev),
+                "specific_probs": torch.zeros((B, 20), dtype=torch.float32, device=dev),
+                "specific_count": torch.zeros((B,), dtype=torch.int32, device=dev)}
 
-    def flush(self) -> int:
-        """Collective: every rank calls it the same number of times.  Returns the number of files written (merge rank)."""
-        import torch.distributed as dist
-        from .parallel import gather_padded
-        with self._lock:
-            files, self.files = self.files, []
-        raw = np.frombuffer(self.pack(files), dtype=np.uint8).copy()
-        local = torch.from_numpy(raw).to(self.device)
-        cap = torch.tensor([local.numel()], dtype=torch.int64, device=self.device)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        got = gather_padded(local, local.numel(), int(cap.item()), dst=self.dst)
-        n = 0
-        if got is not None:
-            for t in got:
-                for path, data in self.unpack(t.cpu().numpy().tobytes()):
-                    _write_bytes(path, data)
-                    n += 1
-        return n
+    def decode_and_write(self, r: int, k: int, buf: torch.Tensor, out: str, writer) -> int:
+        """Merge rank: rank ``r``'s buffer of round ``k`` -> its files.  Returns the number of files submitted."""
+        from .mergetrack import encode_masks_begin, encode_masks_finish
+        from .proposal.driver import custom_resize_shape, results_json
+        seq, names, has_next, (h, w) = self.chunks[r][k]
+        n = len(names)
+        u = self.x.unpack(buf)
+        files = 0
+        flow = u["flow"][:n, :h, :w].cpu().numpy()
+        for i in range(n - (0 if has_next else 1)):
+            writer.submit(_write_flo, os.path.join(out, "flow", seq, names[i] + ".flo"), np.ascontiguousarray(flow[i]))
+            files += 1
+        nh, nw = custom_resize_shape(h, w)
+        scale = (nh * 1.0 / h + nw * 1.0 / w) / 2
+        lists = {}
+        for which in ("general", "specific"):
+            lists[which] = results_json(u[which + "_boxes"][:n].cpu().numpy(), u[which + "_probs"][:n].cpu().numpy(),
+                                        u[which + "_count"][:n].cpu().numpy(), scale, (h, w))
+            for i in range(n):
+                writer.submit(_dump_json, os.path.join(out, which + "_proposals", seq, names[i] + ".json"), lists[which][i])
+                files += 1
+        conf = u["conf"][:n].cpu().numpy()
+        masks = u["masks"]
+        if not masks.is_cuda:
+            masks = masks.to("cuda")
+        for i in range(n):
+            both = lists["general"][i] + lists["specific"][i]
+            writer.submit(_dump_json, os.path.join(out, "combined_proposals", seq, names[i] + ".json"), both)
+            refined = [dict(p) for p in both]
+            handle = encode_masks_begin(masks[i, :len(both), :h, :w].contiguous()) if both else None
 
-    def close(self):
-        pass
+            def finish(refined=refined, handle=handle, c=conf[i], fn=os.path.join(out, "refined_proposals", seq, names[i] + ".json")):
+                if handle is not None:
+                    for q, seg, cv in zip(refined, encode_masks_finish(handle), c):
+                        q["segmentation"] = seg
+                        q["conf_score"] = str(cv)
+                _dump_json(fn, refined)
+            writer.submit(finish)
+            files += 2
+        return files
 
 
 def _self_launch(gpus: int, argv: List[str]) -> int:
@@ -406,11 +540,9 @@ def run(root: str, seq_file: str, flow_weights: str, general_weights: str, speci
     pipe = StreamPipeline(flow_weights, general_weights, specific_weights, refinement_weights, batch, out)
     n = 0
     if gather and world > 1:
-        gw = GatherWriter(torch.device("cuda") if backend == "nccl" else torch.device("cpu"))
-        for k in range(max(len(p) for p in plans)):          # one gather per shard item, empty ones to keep the ranks in step
-            if k < len(plans[rank]):
-                n += pipe.run_sequences(folders, [plans[rank][k]], writer=gw)
-            gw.flush()
+        # one round of the ONE gather per chunk (DeviceGather); every rank runs all rounds, with fillers where it owns nothing
+        dg = DeviceGather(pipe, folders, plans, rank, world, torch.device("cuda"))
+        n = pipe.run_sequences(folders, plans[rank], gather=dg)
     else:
         n = pipe.run_sequences(folders, plans[rank])
     total = n

@@ -324,36 +324,19 @@ def test_result_exchange_async_world8_gloo_with_idle_ranks(T, B, idle):
     assert ok and owners == list(range(-(-T // B))) and n_idle == idle and rounds == -(-(-(-T // B)) // 8)
 
 
-def _gather_writer_worker(rank, world, port, q, root):
+def test_list_chunks_is_the_gpu_free_twin_of_iter_chunks():
+    """--gather: every rank derives every rank's chunk list from the shard plan alone (stream.list_chunks), so the merge rank knows
+    which frames a gathered buffer holds; it must agree with what stream.iter_chunks hands the stages."""
+    import numpy as np
     from premvos_amd import stream
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import numpy as np
-    gw = stream.GatherWriter(torch.device("cpu"))
-    written = 0
-    for item in range(3):                        # three shard items; ranks 2, 5 never have files, rank 7 only in item 1
-        if rank not in (2, 5) and (rank != 7 or item == 1):
-            gw.submit(stream._dump_json, os.path.join(root, f"json/r{rank}_{item}.json"), [{"bbox": [rank, item, 1.5, 2.5], "score": 0.5}])
-            gw.submit(stream._write_flo, os.path.join(root, f"flow/r{rank}_{item}.flo"),
-                      np.full((2, 3, 2), rank + 0.25 * item, np.float32))
-        written += gw.flush()                    # collective: every rank, every item, files or not
-    if rank == 0:
-        q.put(written)
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_gather_writer_flush_world8_with_empty_ranks(tmp_path):
-    import json
-    import numpy as np
-    from premvos_amd.flow.driver import readFlowFile
-    written = _spawn(_gather_writer_worker, 8, str(tmp_path))
-    ranks_items = [(r, i) for i in range(3) for r in range(8) if r not in (2, 5) and (r != 7 or i == 1)]
-    assert written == 2 * len(ranks_items) == len(list(tmp_path.rglob("*.*")))
-    for r, i in ranks_items:                     # only the merge rank created directories / files; every payload intact
-        assert json.load(open(tmp_path / "json" / f"r{r}_{i}.json")) == [{"bbox": [r, i, 1.5, 2.5], "score": 0.5}]
-        assert np.array_equal(readFlowFile(str(tmp_path / "flow" / f"r{r}_{i}.flo")), np.full((2, 3, 2), r + 0.25 * i, np.float32))
+    for n_frames, batch, world in ((13, 2, 8), (5, 8, 2), (16, 4, 3), (1, 2, 2)):
+        images = [f"/v/{t:05d}.jpg" for t in range(n_frames)]
+        for rank in range(world):
+            for _, first, end in P.plan_shards([n_frames], world, rank, batch):
+                a = stream.list_chunks(images, first, end, batch)
+                b = [(names, nxt is not None) for names, frames, nxt in
+                     stream.iter_chunks(images, first, end, batch, lambda fn: np.zeros((2, 2, 3), np.uint8))]
+                assert a == b, (n_frames, batch, world, rank)
 
 
 def _shard8_worker(rank, world, port, q, counts, batch):

@@ -31,7 +31,7 @@ def _fake_pipeline(batch, lanes=2, fail_at=None, seen=None):
     lock = threading.Lock()
 
     def flow(chunk, writer):
-        seq, names, frames, nxt = chunk
+        seq, names, frames, nxt, _stg = chunk
         ids = [int(f[0, 0, 0]) for f in frames] + ([int(nxt[0, 0, 0])] if nxt is not None else [])
         with lock:
             seen["flow"] += list(zip(ids[:-1], ids[1:]))

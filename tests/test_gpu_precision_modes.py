@@ -100,12 +100,13 @@ def test_proposal_and_refinement_bf16x3_stay_within_fp32_tolerances():
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,act,res", [(2, 25, 25, 728, 728, "none", True), (1, 49, 49, 256, 728, "relu", False),
-                                                    (3, 13, 17, 128, 130, "leaky", True), (1, 9, 9, 2048, 256, "relu", False),
+                                                    (3, 13, 17, 128, 136, "leaky", True), (1, 9, 9, 2048, 256, "relu", False),
                                                     (1, 31, 29, 304, 256, "relu", False)])
-def test_split_depthwise_and_pointwise_bf16x3(n, h, w, cin, cout, act, res):
-    """Round 3: premvos_dwconv3x3_f32 with PREMVOS_ACT_SPLIT_BF16 stores {hi, lo} bf16 groups in place of its floats, and
-    premvos_pwconv_bf16x3_split_f32 multiplies them (hi.hi + hi.lo + lo.hi) -- against the fp64 convolution of the fp32
-    depthwise result: fp32-class (3e-5 of the output scale), with ragged M / N tiles, residual, bias, activation."""
+def test_s8_depthwise_and_pointwise_bf16x3(n, h, w, cin, cout, act, res):
+    """Round 4: premvos_dwconv3x3_f32 with PREMVOS_ACT_SPLIT8_BF16 stores the resident split layout S8 ({hi8, lo8} per group of 8
+    channels) in place of its floats, and premvos_conv_bf16x3_s8_f32 multiplies it (hi.hi + hi.lo + lo.hi) -- against the fp64
+    convolution of the fp32 depthwise result: fp32-class (3e-5 of the output scale), with ragged M / N tiles, residual, bias,
+    activation, and an output that is a channel window of a wider buffer."""
     from premvos_amd import _lib, ops
     g = torch.Generator().manual_seed(cin + cout + h)
     x = torch.randn((n, cin, h, w), generator=g)
@@ -120,30 +121,27 @@ def test_split_depthwise_and_pointwise_bf16x3(n, h, w, cin, cout, act, res):
     dwk = torch.zeros((9, cpad), device="cuda")
     dwk[:, :cin] = dw.view(cin, 9).t().cuda()
     bias0 = torch.zeros((cpad,), device="cuda")
-    outs = []
-    for flags in (0, _lib.ACT_SPLIT_BF16):
-        t = ops.NHWC.alloc(n, h, w, cin)
+    plain, split = ops.NHWC.alloc(n, h, w, cin), ops.NHWC.alloc_s8(n, h, w, cin)
+    for t, flags in ((plain, 0), (split, _lib.ACT_SPLIT8_BF16)):
         _lib.check(lib.premvos_dwconv3x3_f32(xin.ptr, xin.ps, n, h, w, cin, dwk.data_ptr(), bias0.data_ptr(), cpad, t.ptr, t.ps, h, w,
                                              1, 1, 1, 1, 0, flags, _lib.current_stream()), "dw")
-        outs.append(t)
-    plain, split = outs
     torch.cuda.synchronize()
-    # decode the split form: every 16 bytes = four bf16 hi, four bf16 lo
-    raw = split.buf.view(torch.int16).view(n, h, w, -1, 8)
-    hi = raw[..., :4].contiguous().view(torch.bfloat16).float().reshape(n, h, w, -1)
-    lo = raw[..., 4:].contiguous().view(torch.bfloat16).float().reshape(n, h, w, -1)
-    ref_dw = plain.buf
+    # decode the S8 form: every 32 bytes = eight bf16 hi, eight bf16 lo
+    raw = split.buf.view(torch.bfloat16).view(n, h, w, -1, 2, 8).float()
+    hi, lo = raw[..., 0, :].reshape(n, h, w, -1)[..., :cin], raw[..., 1, :].reshape(n, h, w, -1)[..., :cin]
+    ref_dw = plain.buf[..., :cin]
     assert torch.equal(hi, ref_dw.to(torch.bfloat16).float())                          # hi = round-to-nearest-even bf16
     assert ((hi + lo) - ref_dw).abs().max().item() <= 2.0 ** -15 * ref_dw.abs().max().item()
-    pk = ops.pack_conv(wt, b, precision="bf16x3")
-    out = ops.NHWC.alloc(n, h, w, cout + 4)
+    assert torch.equal(split.torch(), (hi + lo).permute(0, 3, 1, 2))                   # (NHWC.torch() decodes an S8 buffer)
+    pk = ops.pack_conv_s8(wt, b)
+    out = ops.NHWC.alloc(n, h, w, cout + 8)
     out.buf.fill_(5.0)
     rin = None
     if res:
         rin = ops.NHWC.alloc(n, h, w, cout)
         rin.buf[..., :cout] = r.permute(0, 2, 3, 1).cuda()
     a = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY}[act]
-    ops.pwconv_bf16x3_split(split, pk, out.slice(0, cout), act=a, slope=0.1, res=rin)
+    ops.conv_s8(split, pk, out.slice(0, cout), None, act=a, slope=0.1, res=rin)
     torch.cuda.synchronize()
     ref = F.conv2d(plain.torch().cpu().double(), wt.double(), b.double())
     if res:
@@ -152,86 +150,25 @@ def test_split_depthwise_and_pointwise_bf16x3(n, h, w, cin, cout, act, res):
     got = out.slice(0, cout).torch().cpu().double()
     assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
     assert torch.all(out.buf[..., cout:] == 5.0)                                       # the channel window is respected
+    # the layout flags are checked: an S8 output needs a pixel stride of whole groups
+    bad = ops.NHWC.alloc(n, h, w, 4)
+    assert lib.premvos_dwconv3x3_f32(xin.ptr, xin.ps, n, h, w, 4, dwk.data_ptr(), bias0.data_ptr(), 4, bad.ptr, bad.ps, h, w, 1, 1, 1, 1, 0,
+                                     _lib.ACT_SPLIT8_BF16, _lib.current_stream()) != 0
+    assert lib.premvos_dwconv3x3_f32(xin.ptr, xin.ps, n, h, w, cin, dwk.data_ptr(), bias0.data_ptr(), cpad, plain.ptr, plain.ps, h, w, 1, 1, 1,
+                                     1, 0, 0x100, _lib.current_stream()) != 0          # round 3's flag is gone
 
 
-def _decode_split(buf, c):
-    """{hi(4 x bf16), lo(4 x bf16)} groups -> (hi, lo) float tensors [..., c]."""
-    raw = buf.view(torch.int16).view(*buf.shape[:-1], -1, 8)
-    hi = raw[..., :4].contiguous().view(torch.bfloat16).float().reshape(*buf.shape[:-1], -1)[..., :c]
-    lo = raw[..., 4:].contiguous().view(torch.bfloat16).float().reshape(*buf.shape[:-1], -1)[..., :c]
-    return hi, lo
-
-
-@pytest.mark.parametrize("n,h,w,feat", [(2, 23, 30, 128), (1, 14, 14, 256)])
-def test_split_bottleneck_chain_bf16x3(n, h, w, feat):
-    """Round 3, proposal net in bf16x3 mode: the 3x3 conv2 of a bottleneck runs as fp32 Winograd F(4x4,3x3) and stores {hi, lo} groups
-    (PREMVOS_ACT_SPLIT_BF16 on premvos_conv2d_f32, tile_hint 4); conv3 (1x1 + residual + ReLU) multiplies them on
-    premvos_pwconv_bf16x3_split_f32 and writes its output twice, fp32 and split; the next conv1 reads the split copy.  Against the
-    plain fp32 launches of the same layers / the fp64 convolution."""
-    from premvos_amd import _lib, ops
-    g = torch.Generator().manual_seed(feat + h)
-    x = torch.randn((n, feat, h, w), generator=g)
-    w2 = torch.randn((feat, feat, 3, 3), generator=g) * (2.0 / (9 * feat)) ** 0.5
-    w3 = torch.randn((4 * feat, feat, 1, 1), generator=g) * (2.0 / feat) ** 0.5
-    w1 = torch.randn((feat, 4 * feat, 1, 1), generator=g) * (2.0 / (4 * feat)) ** 0.5
-    b2, b3, b1 = (torch.randn((c,), generator=g) * 0.1 for c in (feat, 4 * feat, feat))
-    sc = torch.randn((n, 4 * feat, h, w), generator=g)
-    xin = ops.NHWC.alloc(n, h, w, feat)
-    xin.buf[..., :feat] = x.permute(0, 2, 3, 1).cuda()
-    scin = ops.NHWC.alloc(n, h, w, 4 * feat)
-    scin.buf[..., :4 * feat] = sc.permute(0, 2, 3, 1).cuda()
-    pk2 = ops.pack_conv(w2, b2, precision="fp32")
-    assert pk2.wgt_wino4 is not None
-    outs = []
-    for flag in (0, _lib.ACT_SPLIT_BF16):
-        t2 = ops.NHWC.alloc(n, h, w, feat)
-        d = ops.conv_desc(xin, pk2, t2, pad=(1, 1), act=ops.ACT_RELU, tile_hint=4)
-        ws = torch.empty((ops.workspace_bytes(d) + 3) // 4, dtype=torch.float32, device="cuda")
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        d.act |= flag
-        ops.run_desc(d)
-        outs.append(t2)
-    torch.cuda.synchronize()
-    plain2, split2 = outs
-    hi, lo = _decode_split(split2.buf, feat)
-    assert torch.equal(hi, plain2.buf[..., :feat].to(torch.bfloat16).float())
-    assert ((hi + lo) - plain2.buf[..., :feat]).abs().max().item() <= 2.0 ** -15 * plain2.buf.abs().max().item()
-    # the split flag is refused on every other kernel family (nothing would read such an output correctly by accident)
-    d = ops.conv_desc(xin, pk2, ops.NHWC.alloc(n, h, w, feat), pad=(1, 1), act=ops.ACT_RELU | _lib.ACT_SPLIT_BF16, tile_hint=(128 << 16) | 128)
-    with pytest.raises(_lib.PremvosError, match="SPLIT_BF16"):
-        ops.run_desc(d)
-    # conv3: split in, fp32 + split out
-    pk3 = ops.pack_conv(w3, b3, precision="bf16x3")
-    y, ys = ops.NHWC.alloc(n, h, w, 4 * feat), ops.NHWC.alloc(n, h, w, 4 * feat)
-    ops.pwconv_bf16x3_split(split2, pk3, y, act=ops.ACT_RELU, res=scin, out_split=ys)
-    torch.cuda.synchronize()
-    ref3 = F.relu(F.conv2d(plain2.torch().cpu().double(), w3.double(), b3.double()) + sc.double())
-    got3 = y.torch().cpu().double()
-    assert (got3 - ref3).abs().max().item() < 3e-5 * max(1.0, ref3.abs().max().item())
-    hi, lo = _decode_split(ys.buf, 4 * feat)
-    assert torch.equal(hi, y.buf[..., :4 * feat].to(torch.bfloat16).float())
-    assert ((hi + lo) - y.buf[..., :4 * feat]).abs().max().item() <= 2.0 ** -15 * y.buf.abs().max().item()
-    # the next conv1 on the split copy
-    pk1 = ops.pack_conv(w1, b1, precision="bf16x3")
-    t1 = ops.NHWC.alloc(n, h, w, feat)
-    ops.pwconv_bf16x3_split(ys, pk1, t1, act=ops.ACT_RELU)
-    torch.cuda.synchronize()
-    ref1 = F.relu(F.conv2d(y.torch().cpu().double(), w1.double(), b1.double()))
-    assert (t1.torch().cpu().double() - ref1).abs().max().item() < 3e-5 * max(1.0, ref1.abs().max().item())
-
-
-def test_proposal_bf16x3_plan_uses_the_split_chain(monkeypatch):
-    """The bf16x3 proposal plan: 3x3 layers on the fp32 kernels (F(4x4,3x3) where the table says so -- forced here, the maps of a
-    small image are below the table's threshold), conv3 / conv1 of those blocks on the split kernel; same feature map as the fp32
-    net on a reduced-depth net."""
+def test_proposal_bf16x3_plan_uses_the_s8_chains(monkeypatch):
+    """The bf16x3 proposal plan: from group 1 on the bottleneck chains live in the S8 layout (conv1 / conv2 / conv3 on
+    csrc/conv_bf16x3_s8.hip, S8 residuals, no fp32 copy of the block outputs between a group's first and last block); group 0, the
+    RPN 3x3 and the heads on the fp32 kernels; same feature map as the fp32 net on a reduced-depth net."""
     from premvos_amd import synth
     from premvos_amd.proposal.model import ProposalNet
-    monkeypatch.setenv("PREMVOS_FORCE_KERNEL", "wino4")
     wts = synth.proposal_weights(0, num_blocks=(1, 2, 3, 2))
     img = synth.clip_frames(0, 1, 256, 384).cuda()
     nets = {p: ProposalNet(wts, num_blocks=(1, 2, 3, 2), precision=p, use_graph=False) for p in ("fp32", "bf16x3")}
     plans = {p: nets[p].run_resized(img) for p in nets}
     torch.cuda.synchronize()
-    assert plans["bf16x3"].split_layers >= 4 and plans["fp32"].split_layers == 0
+    assert plans["bf16x3"].split_layers == 3 * (2 + 3 + 2) + 3 and plans["fp32"].split_layers == 0       # conv1-3 of groups 1-3 + 3 shortcuts
     fa, fb = plans["fp32"].featuremap.torch(), plans["bf16x3"].featuremap.torch()
     assert (fa - fb).abs().max().item() < 1e-3 * fa.abs().max().item()

@@ -1,5 +1,4 @@
-"""Dev tool: csrc/conv_bf16x3_s8.hip per layer shape and tile, against the fp32 implicit GEMM / Winograd kernels the table picks and the
-round-3 split kernel.  TFLOP/s-equivalent = algorithmic 2 M K N / time; issued fraction of the bf16 pipe = 3x that / 2500."""
+"""Dev tool: csrc/conv_bf16x3_s8.hip per layer shape and tile, against the fp32 implicit GEMM / Winograd kernel the table picks.  TFLOP/s-equivalent = algorithmic 2 M K N / time; issued fraction of the bf16 pipe = 3x that / 2500."""
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from premvos_amd import ops, _lib
@@ -33,6 +32,12 @@ SHAPES = [  # name, n, h, w, cin, cout, k, pad
     ("conv5 3x3 512->512 1600 rois", 1600, 7, 7, 512, 512, 3, 1),
     ("conv5 conv1 2048->512 1600 rois", 1600, 7, 7, 2048, 512, 1, 0),
     ("pwc L2 conv2_1 3x3 248->128 B16", 16, 128, 224, 248, 128, 3, 1),
+    # K sweep at the middle flow's M and N: time(K) = fixed (prologue + epilogue + tile rounds) + K / rate
+    ("ksweep 256->728 M=100k", 160, 25, 25, 256, 728, 1, 0),
+    ("ksweep 1456->728 M=100k", 160, 25, 25, 1456, 728, 1, 0),
+    ("ksweep 2912->728 M=100k", 160, 25, 25, 2912, 728, 1, 0),
+    ("ksweep 728->768 M=100k", 160, 25, 25, 728, 768, 1, 0),
+    ("ksweep 728->768 M=131k (512 row tiles)", 128, 32, 32, 728, 768, 1, 0),
 ]
 only = os.environ.get("S8_ONLY")
 rows = []
@@ -72,14 +77,6 @@ for name, n, h, w, cin, cout, k, pad in SHAPES:
                 row[f"t{tile}_err"] = float((out.buf - ref).abs().max() / ref.abs().max())
     best = max(v for kk, v in row.items() if kk.endswith("_tf") and kk.startswith("t"))
     row["best_s8_tf"], row["best_issued_frac_of_bf16_pipe"], row["speedup_vs_fp32"] = best, round(3 * best / 2500, 3), round(best / row["fp32_tf"], 2)
-    if k == 1 and cin % 32 == 0 or k == 1:
-        try:      # the round-3 split kernel ({hi4, lo4} groups), for reference
-            pk3 = ops.pack_conv(wt, torch.zeros(cout), precision="bf16x3")
-            tt = ops.NHWC.alloc(n, h, w, cin)
-            told = timeit(lambda: ops.pwconv_bf16x3_split(tt, pk3, out, act=ops.ACT_RELU))
-            row["r03_split_us"], row["r03_split_tf"] = round(told, 1), round(flops / told / 1e6, 1)
-        except Exception as e:       # noqa: BLE001
-            row["r03_split"] = str(e)[:60]
     rows.append(row)
     print(json.dumps(row), flush=True)
     del x, xs, out, out8
