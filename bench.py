@@ -317,24 +317,45 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32"):
             "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
 
 
+RIDGE_F32 = PEAK_F32_TFLOPS * 1e12 / 6.29e12      # FLOP per HBM byte above which an fp32 conv is MFMA-bound (6.29 TB/s achievable)
+
+
 def _family_split(items, tot, mult):
+    """`frac` split by what bounds a layer.  Winograd layers issue 16/36 or 36/144 of their algorithmic FLOPs; of the layers that
+    multiply every algorithmic FLOP (implicit GEMM incl. k-slab / tail-split launches, the streaming pointwise kernel, the 1-2
+    channel direct heads) those whose ALGORITHMIC intensity -- 2 M K N over compulsory bytes, ops.algorithmic_bytes -- lies below
+    the ridge (25 FLOP/B) cannot reach the MFMA roofline whatever the kernel does (a 64 -> 256 pointwise layer with a residual is
+    14 FLOP/B: its ceiling is 0.57 of the fp32 MFMA peak): they are priced against HBM instead."""
     def issue(h):
         return 16.0 / 36.0 if h in (2, 3) else 0.25 if h == 4 else 1.0
-    fl_i = t_i = fl_w = is_w = t_w = 0.0
-    for (_, _, _, f, _, d), t, m in zip(items, tot, mult):
+    fl_i = t_i = fl_w = is_w = t_w = fl_m = t_m = by_h = t_h = fl_h = 0.0
+    for (_, _, _, f, by, d), t, m in zip(items, tot, mult):
         if d.tile_hint in (2, 3, 4):
             fl_w += f
             is_w += f * issue(d.tile_hint)
             t_w += t * m
+            continue
+        fl_i += f
+        t_i += t * m
+        if f / max(by, 1.0) >= RIDGE_F32:
+            fl_m += f
+            t_m += t * m
         else:
-            fl_i += f
-            t_i += t * m
-    out = {"igemm_family_tflops": round(fl_i / (t_i * 1e-3) / 1e12, 2) if t_i else None,
-           "igemm_family_frac": round(fl_i / (t_i * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4) if t_i else None,
-           "igemm_family_share_of_conv_time": round(t_i / (t_i + t_w), 4) if t_i + t_w else None,
-           "winograd_algorithmic_tflops": round(fl_w / (t_w * 1e-3) / 1e12, 2) if t_w else None,
-           "winograd_issued_frac": round(is_w / (t_w * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4) if t_w else None}
-    return out
+            by_h += by
+            fl_h += f
+            t_h += t * m
+    tf = lambda fl, t: round(fl / (t * 1e-3) / 1e12, 2) if t else None          # noqa: E731
+    return {"igemm_family_tflops": tf(fl_i, t_i),
+            "igemm_family_frac": round(fl_i / (t_i * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4) if t_i else None,
+            "igemm_family_share_of_conv_time": round(t_i / (t_i + t_w), 4) if t_i + t_w else None,
+            "igemm_mfma_bound_layers": {"tflops": tf(fl_m, t_m), "frac": round(fl_m / (t_m * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4) if t_m else None,
+                                        "share_of_conv_time": round(t_m / (t_i + t_w), 4) if t_i + t_w else None},
+            "igemm_hbm_bound_layers": {"what": f"algorithmic intensity < {RIDGE_F32:.0f} FLOP/B: priced against HBM",
+                                       "algorithmic_GB_per_s": round(by_h / (t_h * 1e-3) / 1e9, 1) if t_h else None,
+                                       "frac_of_6290_GB_per_s": round(by_h / (t_h * 1e-3) / 6.29e12, 4) if t_h else None,
+                                       "tflops": tf(fl_h, t_h), "share_of_conv_time": round(t_h / (t_i + t_w), 4) if t_i + t_w else None},
+            "winograd_algorithmic_tflops": tf(fl_w, t_w),
+            "winograd_issued_frac": round(is_w / (t_w * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4) if t_w else None}
 
 
 def self_launch(a) -> int:
