@@ -45,6 +45,16 @@ for prec in mixed-bf16x3 mixed-bf16; do
   grep '^{' "$OUT/${TAG}_bench_$prec.log" | tail -1 > "$OUT/${TAG}_bench_$prec.json"
 done
 python tools/layer_table.py > "$OUT/${TAG}_layer_table.txt" 2>&1
+# 7. round 4: the bf16x3 mode on the resident S8 layout -- per-layer table, rocprofv3 kernel stats (serial stages), the kernel per
+#    layer shape and tile against the fp32 kernels, configs[4]'s 1080p shape in both arithmetics; the merge-shaped serial loop
+LT_PRECISION=bf16x3 python tools/layer_table.py > "$OUT/${TAG}_layer_table_bf16x3.txt" 2>&1
+tools/dev/prof_mixed.sh "$TAG"
+python tools/dev/s8_bench.py > "$OUT/${TAG}_s8_bench.jsonl" 2> /dev/null
+for prec in fp32 mixed-bf16x3; do
+  python bench.py --frame 1080p --precision $prec --steps 5 --warmup 2 --file-to-file 0 > "$OUT/${TAG}_bench_1080p_$prec.log" 2>&1
+  grep '^{' "$OUT/${TAG}_bench_1080p_$prec.log" | tail -1 > "$OUT/${TAG}_bench_1080p_$prec.json"
+done
+python tools/time_merge_loop.py --out "$OUT/${TAG}_merge_loop.json" > /dev/null 2>&1
 python bench.py > "$OUT/${TAG}_bench_fp32.log" 2>&1
 grep '^{' "$OUT/${TAG}_bench_fp32.log" | tail -1 > "$OUT/${TAG}_bench_fp32.json"
 # keep only the small summaries (the traces are tens of MB)
