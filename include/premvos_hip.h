@@ -298,6 +298,11 @@ int premvos_refine_output_f32(const float* logits, int32_t logits_ps, int32_t lh
  * (bench.py: roofline.mfma_ceiling_measured). */
 int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void* stream);
 
+/* Order-independent 64-bit digest of the 4-byte words of a pixel-major window [pixels][c] with pixel stride ps (words): the plan-time
+ * tuner compares the outputs of configurations that must be bit-identical (same numerics key) before it lets a stopwatch choose
+ * between them (premvos_amd/ops.py::_time_cands).  *out_u64 (device) receives the digest. */
+int premvos_digest_u64(const void* buf, int64_t pixels, int32_t c, int32_t ps, void* out_u64, void* stream);
+
 /* Host-side utility (no GPU work): CRC-32C of a host buffer -- the checksum of TensorFlow tensor-bundle checkpoints,
  * which premvos_amd/weights.py reads and writes without TensorFlow (proposal_net/train.py:655, core/Saver.py:33-48). */
 uint32_t premvos_crc32c_host(const void* data, int64_t n);

@@ -980,4 +980,32 @@ extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* 
   return premvos::check_launch("mfma_f32_calibrate");
 }
 
-extern "C" int premvos_abi_version(void) { return 12; }   // bump with every change of include/premvos_hip.h
+namespace {
+// order-independent 64-bit digest of a strided pixel-major window: sum over (pixel, channel) of word * (2 * position + 1)
+__global__ __launch_bounds__(256) void digest_kernel(const unsigned* __restrict__ p, const long pixels, const int c, const int ps,
+                                                     unsigned long long* out) {
+  unsigned long long acc = 0;
+  const long total = pixels * c;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pix = i / c;
+    const int ch = (int)(i - pix * c);
+    acc += (unsigned long long)p[pix * ps + ch] * (unsigned long long)(2 * i + 1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+}  // namespace
+
+extern "C" int premvos_digest_u64(const void* buf, int64_t pixels, int32_t c, int32_t ps, void* out_u64, void* stream) {
+  PV_REQUIRE(buf != nullptr && out_u64 != nullptr && pixels > 0 && c > 0 && ps >= c, "digest: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(out_u64, 0, 8, s) != hipSuccess) return premvos::fail(PREMVOS_ELAUNCH, "digest: memset failed");
+  const long total = pixels * c;
+  const int blocks = (int)(total / 256 / 8 + 1 < 2048 ? total / 256 / 8 + 1 : 2048);
+  hipLaunchKernelGGL(digest_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const unsigned*>(buf), (long)pixels, c, ps,
+                     static_cast<unsigned long long*>(out_u64));
+  return premvos::check_launch("digest");
+}
+
+extern "C" int premvos_abi_version(void) { return 13; }   // bump with every change of include/premvos_hip.h

@@ -84,9 +84,27 @@ __global__ __launch_bounds__(256) void refine_input_kernel(const uint8_t* __rest
 
 // The store of one (pixel, 4-channel unit) result: floats, or -- PREMVOS_ACT_SPLIT8_BF16 (bit 9 of `act`) -- half of a group of the
 // resident S8 layout of the bf16x3 mode (common.h: store_split4; csrc/conv_bf16x3_s8.hip reads it by LDS-DMA)
+constexpr int DW_PAIRED = 0x400;     // internal flag of the launcher: an even number of 4-channel units per pixel -- lanes 2j and 2j + 1 own the
+                                     // two halves of one S8 group and can swap a half by DPP: ONE 16-byte store per lane instead of two 8-byte ones
 __device__ __forceinline__ void store_unit(float* pixel, const int cg, const float4 r, const int act) {
-  if (act & PREMVOS_ACT_SPLIT8_BF16) premvos::store_split4(reinterpret_cast<char*>(pixel), cg, r);
-  else *reinterpret_cast<float4*>(pixel + cg * 4) = r;
+  if (act & PREMVOS_ACT_SPLIT8_BF16) {
+    if (act & DW_PAIRED) {
+      float4 l;
+      const uint2 h = premvos::bf16_hi4(r, l);
+      const uint2 lo = premvos::bf16_rn4(l);
+      const bool odd = cg & 1;
+      const uint2 send = odd ? h : lo;                   // the even lane stores the hi half {h_even, h_odd}, the odd lane the lo half
+      uint2 recv;                                        // quad_perm [1, 0, 3, 2]: neighbours swap (both lanes of a pair are always active together)
+      recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);
+      recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+      char* g = reinterpret_cast<char*>(pixel) + (cg >> 1) * 32;
+      *reinterpret_cast<uint4*>(g + (odd ? 16 : 0)) = odd ? make_uint4(recv.x, recv.y, lo.x, lo.y) : make_uint4(h.x, h.y, recv.x, recv.y);
+    } else {
+      premvos::store_split4(reinterpret_cast<char*>(pixel), cg, r);
+    }
+  } else {
+    *reinterpret_cast<float4*>(pixel + cg * 4) = r;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -477,6 +495,7 @@ extern "C" int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, 
   PV_REQUIRE((act & ~0xff & ~PREMVOS_ACT_SPLIT8_BF16) == 0, "dwconv3x3: unknown output-layout flags");
   PV_REQUIRE(!(act & PREMVOS_ACT_SPLIT8_BF16) || (out_ps % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31u) == 0),
              "dwconv3x3: an S8 output needs out_ps %% 8 == 0 and a 32-byte aligned channel window");
+  if ((act & PREMVOS_ACT_SPLIT8_BF16) && (c_pad / 4) % 2 == 0) act |= DW_PAIRED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (stride == 1 && (wo + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3) &&
       (ho + dilation - 1) / dilation >= (dilation == 1 ? 8 : 3)) {   // register-tiled fast path (stride 2: row kernel wins)

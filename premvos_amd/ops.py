@@ -493,11 +493,29 @@ def _entry_for(d: ConvDesc):
     return cand
 
 
+def _out_digest(d: ConvDesc, lib, stream) -> int:
+    """64-bit digest of the output window a launch of ``d`` wrote (premvos_digest_u64), on the host."""
+    buf = torch.zeros(1, dtype=torch.int64, device="cuda")
+    w = d.cout if d.out_mode == OUT_NHWC else d.cout_ps
+    px = d.n * d.ho * d.wo * (1 if d.out_mode == OUT_NHWC else 4)
+    _lib.check(lib.premvos_digest_u64(d.out, px, w, d.out_ps, buf.data_ptr(), stream), "digest")
+    return int(buf.item())
+
+
 def _time_cands(d: ConvDesc, cands, lib, stream, reps):
+    """The fastest of ``cands`` by wall clock -- among candidates whose output is what their numerics key promises: a candidate that
+    shares its key with an earlier one but writes different bits (a kernel bug, an uncovered shape) is dropped, loudly (ADVICE r03:
+    timing alone once offered a configuration whose grid left rows unwritten)."""
     best, best_t = None, float("inf")
+    ref_digest: dict = {}
     for cand in cands:
         d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = cand
         if lib.premvos_conv2d_f32(C.byref(d), stream) != 0:
+            continue
+        key, dig = numerics_key(d, cand), _out_digest(d, lib, stream)
+        if ref_digest.setdefault(key, dig) != dig:
+            import warnings
+            warnings.warn(f"conv configuration {cand} of signature {_sig(d)} does not reproduce the output of its numerics class: dropped")
             continue
         t = float("inf")
         for _ in range(2):              # best of two bursts: a clock / scheduling hiccup must not pick the config

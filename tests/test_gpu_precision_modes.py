@@ -172,3 +172,30 @@ def test_proposal_bf16x3_plan_uses_the_s8_chains(monkeypatch):
     assert plans["bf16x3"].split_layers == 3 * (2 + 3 + 2) + 3 and plans["fp32"].split_layers == 0       # conv1-3 of groups 1-3 + 3 shortcuts
     fa, fb = plans["fp32"].featuremap.torch(), plans["bf16x3"].featuremap.torch()
     assert (fa - fb).abs().max().item() < 1e-3 * fa.abs().max().item()
+
+
+@pytest.mark.parametrize("cin,stride,rate", [(20, 1, 1), (728, 1, 1), (64, 2, 1), (2048, 1, 6), (12, 1, 2)])
+def test_s8_depthwise_store_paths(cin, stride, rate):
+    """The S8 output of the three depthwise kernels (tile / row / per-pixel): with an even number of 4-channel units per pixel the
+    two lanes of a group swap a half by DPP and store 16 bytes each, with an odd number every lane stores its two 8-byte halves;
+    both decode to exactly bf16 hi + bf16 lo of the fp32 result."""
+    from premvos_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin)
+    n, h, w = 2, 26, 31
+    ho, wo = (h + 1) // stride if stride == 2 else h, (w + 1) // stride if stride == 2 else w
+    x = ops.NHWC.alloc(n, h, w, cin)
+    x.buf[..., :cin] = torch.randn((n, h, w, cin), generator=g).cuda()
+    cpad = (cin + 3) // 4 * 4
+    dwk = torch.zeros((9, cpad), device="cuda")
+    dwk[:, :cin] = (torch.randn((9, cin), generator=g) * 0.3).cuda()
+    b0 = (torch.randn((cpad,), generator=g) * 0.1).cuda()
+    lib = _lib.load()
+    plain, s8 = ops.NHWC.alloc(n, ho, wo, cin), ops.NHWC.alloc_s8(n, ho, wo, cin)
+    for t, fl in ((plain, ops.ACT_RELU), (s8, ops.ACT_RELU | _lib.ACT_SPLIT8_BF16)):
+        _lib.check(lib.premvos_dwconv3x3_f32(x.ptr, x.ps, n, h, w, cin, dwk.data_ptr(), b0.data_ptr(), cpad, t.ptr, t.ps, ho, wo, stride,
+                                             rate, rate if stride == 1 else 1, rate if stride == 1 else 1, 1, fl, _lib.current_stream()), "dw")
+    torch.cuda.synchronize()
+    ref = plain.buf[..., :cin]
+    hi = ref.to(torch.bfloat16).float()
+    lo = (ref - hi).to(torch.bfloat16).float()
+    assert torch.equal(s8.torch(), (hi + lo).permute(0, 3, 1, 2))

@@ -98,3 +98,42 @@ def test_rule_choice_is_deterministic_and_two_tuning_passes_agree(layer, monkeyp
         ops._TUNE_CACHE.clear()
         ops._TUNE_CACHE.update(saved)
         ops._TUNE_STATE.update(state)
+
+
+def test_tuner_compares_outputs_before_it_times(monkeypatch):
+    """`_time_cands` chose by time alone.  Now every candidate's output window is digested on the GPU
+    (premvos_digest_u64) and a candidate that shares its numerics key with an earlier one but wrote other bits is dropped."""
+    import ctypes as C
+    import warnings
+    from premvos_amd import _lib, ops
+    lib, st = _lib.load(), _lib.current_stream()
+    g = torch.Generator().manual_seed(3)
+    x = ops.NHWC.alloc(1, 40, 41, 128)
+    x.buf.copy_(torch.randn(x.buf.shape, generator=g))
+    pk = ops.pack_conv(torch.randn((256, 128, 1, 1), generator=g) * 0.1, torch.randn((256,), generator=g))
+    out = ops.NHWC.alloc(1, 40, 41, 256)
+    d = ops.conv_desc(x, pk, out, act=ops.ACT_RELU)
+    cands = [((128 << 16) | 128, 16, -1, 0, 0), (5, 0, -1, 0, 0), ((64 << 16) | 64, 16, -1, 0, 0)]
+    d.tile_hint, d.stage_k, d.split_k, d.tail_m_tiles, d.tail_split_k = cands[0]
+    ops.run_desc(d)
+    a = ops._out_digest(d, lib, st)
+    assert a == ops._out_digest(d, lib, st) and a != 0
+    out.buf[0, 7, 9, 3] += 1.0
+    assert ops._out_digest(d, lib, st) != a                                   # one word changed: another digest
+    assert ops._time_cands(d, cands, lib, st, 2) in cands                     # bit-identical candidates: all kept, one wins
+    # a "candidate" of the same numerics class that writes other bits: simulated by a library call that scribbles afterwards
+    real = lib.premvos_conv2d_f32
+    calls = {"n": 0}
+
+    class Scribbler:
+        def __call__(self, dref, stream):
+            rc = real(dref, stream)
+            calls["n"] += 1
+            if d.tile_hint == 5:
+                out.buf[0, 0, 0, 0] = 12345.0
+            return rc
+    monkeypatch.setattr(lib, "premvos_conv2d_f32", Scribbler(), raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        best = ops._time_cands(d, cands, lib, st, 2)
+    assert best in (cands[0], cands[2]) and any("does not reproduce" in str(m.message) for m in w)
