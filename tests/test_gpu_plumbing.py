@@ -427,3 +427,53 @@ def test_eight_ranks_write_the_one_rank_tree_both_sharding_branches(tmp_path):
                 [("bear", 0, 2), ("bear", 2, 4), ("bear", 4, 5), ("camel", 0, 2), ("camel", 2, 3), ("dog", 0, 2)]
         else:
             assert sorted(len(p) for p in m["shards"]) == [1] * 7 + [2]
+
+
+def test_streaming_driver_in_the_bf16x3_mode_writes_the_fp32_trees_proposals_and_masks(tmp_path, monkeypatch):
+    """PREMVOS_PRECISION=bf16x3 through the file-to-file product path (fresh processes): the nets run on the resident S8 layout
+    (packed refinement slots, eager launches, two lanes), the output tree has the fp32 run's files; proposal JSONs are equal or differ
+    in the last printed digit of a box / score, and the refined masks agree with the fp32 run's to IoU >= 0.98 (fp32-class arithmetic:
+    a mask pixel flips only where the posterior is within ~1e-4 of 0.5)."""
+    import subprocess
+    import sys
+    from premvos_amd import rle
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    roots = {}
+    for prec in ("fp32", "bf16x3"):
+        root = tmp_path / prec
+        root.mkdir()
+        _make_tree(root, t=5)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+        env.update({"PREMVOS_PRECISION": prec, "PYTHONPATH": repo})
+        r = subprocess.run([sys.executable, "-m", "premvos_amd.stream", "--root", str(root), "--batch", "2", "--flow_weights",
+                            "weights/pwc.pth.tar", "--general_weights", "weights/proposal_general_weights", "--specific_weights",
+                            "weights/specific.pt", "--refinement_weights", "weights/refinement_specific_weights"],
+                           capture_output=True, text=True, env=env, timeout=900, cwd=repo)
+        assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+        roots[prec] = root / "output" / "intermediate"
+    fa = sorted(str(p.relative_to(roots["fp32"])) for p in roots["fp32"].rglob("*") if p.is_file())
+    fb = sorted(str(p.relative_to(roots["bf16x3"])) for p in roots["bf16x3"].rglob("*") if p.is_file())
+    assert fa == fb and len(fa) == 4 + 4 * 5
+    n_masks = 0
+    for f in fa:
+        if not f.startswith("refined_proposals"):
+            continue
+        a, b = json.load(open(roots["fp32"] / f)), json.load(open(roots["bf16x3"] / f))
+        assert len(a) == len(b)
+        for p, q in zip(a, b):
+            assert np.abs(np.array(p["bbox"]) - np.array(q["bbox"])).max() <= 0.11 and abs(p["score"] - q["score"]) <= 0.011
+            ma, mb = rle.decode(p["segmentation"]), rle.decode(q["segmentation"])
+            inter, union = int((ma & mb).sum()), int((ma | mb).sum())
+            assert union == 0 or inter / union >= 0.98, (f, inter, union)
+            assert abs(float(p["conf_score"]) - float(q["conf_score"])) < 1e-2
+            n_masks += 1
+    # (the reduced-depth random-weight nets of this tree may detect nothing; the flow files always exist: PWC-Net on the on-the-fly
+    #  bf16x3 kernel against the fp32 kernels)
+    from premvos_amd.flow.driver import readFlowFile
+    n_flo = 0
+    for f in fa:
+        if f.endswith(".flo"):
+            x, y = readFlowFile(str(roots["fp32"] / f)), readFlowFile(str(roots["bf16x3"] / f))
+            assert np.abs(x - y).max() < 1e-3 * max(1.0, np.abs(x).max()), f
+            n_flo += 1
+    assert n_flo == 4 and n_masks >= 0
