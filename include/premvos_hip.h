@@ -121,6 +121,22 @@ int premvos_conv2d_f32(const premvos_conv_desc* d, void* stream);
  * a second kernel sums in a fixed order before the fused epilogue (deterministic, unlike atomics). */
 int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* d);
 
+/* Winograd F(4x4,3x3) with a KEPT input-transform slab, for DenseNet blocks: PWC-Net's flow estimators
+ * (PWCNet.py:201-264, `x = torch.cat((self.convL_i(x), x), 1)`) feed layer i the concat of everything layers 0 ... i-1
+ * produced, so premvos_conv2d_f32 with tile_hint 4 transforms the same channels again in every layer of a level.  Here the
+ * caller owns ONE slab per concat buffer, V[36][tiles][v_pitch] floats (tiles = n * ceil(ho/4) * ceil(wo/4); slab channel =
+ * channel of the concat buffer), and every layer adds only what is new:
+ *   d        the layer's descriptor as for premvos_conv2d_f32 (wgt_wino4 packed; `in` = first channel of its input window;
+ *            stage_k = GEMM block as with tile_hint 4); d->workspace holds the M slab: 36 * tiles * roundup(cout, 64 or 128) floats
+ *   v_c0     slab channel of the window's first channel; the GEMM reads slab channels [v_c0, v_c0 + Kp), Kp = roundup(cin_pad, 16)
+ *   t_cn     channels [0, t_cn) of the window are transformed by this call (0: everything is in the slab already); channels
+ *            >= cin_pad are written as zeros, so t_cn = Kp on the first layer of a level zero-fills the K padding for all
+ *            (every window of a level ends at the same channel)
+ * v_pitch, v_c0, t_cn: multiples of 4, v_c0 + Kp <= v_pitch, t_cn <= Kp.  Same V values, same GEMM, same output transform as the
+ * self-contained form: bit-identical results (tests/test_gpu_conv_wino.py).  PREMVOS_EINVAL if the layer is not an F(4x4) layer. */
+int premvos_conv_wino4_slab_f32(const premvos_conv_desc* d, float* vslab, int64_t vslab_bytes, int32_t v_pitch, int32_t v_c0, int32_t t_cn,
+                                void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * PWC-Net cost volume, the only first-party native kernel of the reference:
  *   corr_cuda_forward  correlation_package/src/corr_cuda.c:7-82

@@ -101,6 +101,8 @@ __device__ __forceinline__ void store_split4(char* pixel, const int cg, const fl
   *reinterpret_cast<uint2*>(g + 16) = bf16_rn4(l);
 }
 
+int conv_desc_check(const premvos_conv_desc& d);      // conv_igemm_f32.hip: what every dense-conv entry requires of a descriptor
+
 }  // namespace premvos
 
 #define PV_REQUIRE(cond, ...) \

@@ -847,9 +847,8 @@ inline void pick_tile(const premvos_conv_desc& d, int* bm, int* bn) {
 
 }  // namespace
 
-extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
-  PV_REQUIRE(dp != nullptr, "conv2d: null descriptor");
-  const premvos_conv_desc& d = *dp;
+// What every dense-conv entry point requires of a descriptor (premvos_conv2d_f32, premvos_conv_wino4_slab_f32).
+int premvos::conv_desc_check(const premvos_conv_desc& d) {
   PV_REQUIRE(d.in && d.wgt && d.out, "conv2d: null tensor pointer");
   PV_REQUIRE(d.n > 0 && d.h > 0 && d.w > 0 && d.cin > 0 && d.ho > 0 && d.wo > 0 && d.cout > 0,
              "conv2d: non-positive dimension");
@@ -871,6 +870,13 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   else
     PV_REQUIRE(d.out_mode == PREMVOS_OUT_NHWC, "conv2d: bad out_mode");
   PV_REQUIRE((long)d.n * d.ho * d.wo < (1L << 31), "conv2d: too many output pixels");
+  return PREMVOS_OK;
+}
+
+extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
+  PV_REQUIRE(dp != nullptr, "conv2d: null descriptor");
+  const premvos_conv_desc& d = *dp;
+  if (const int rc = premvos::conv_desc_check(d)) return rc;
 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d.precision != PREMVOS_PREC_F32) return premvos::conv2d_bf16(d, s);
@@ -1008,4 +1014,4 @@ extern "C" int premvos_digest_u64(const void* buf, int64_t pixels, int32_t c, in
   return premvos::check_launch("digest");
 }
 
-extern "C" int premvos_abi_version(void) { return 13; }   // bump with every change of include/premvos_hip.h
+extern "C" int premvos_abi_version(void) { return 14; }   // bump with every change of include/premvos_hip.h

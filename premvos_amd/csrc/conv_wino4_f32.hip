@@ -46,12 +46,14 @@ __device__ __forceinline__ void bt6(const float4& d0, const float4& d1, const fl
   t[5] = 4.f * d1 - 5.f * d3 + d5;
 }
 
-// V[c = 6 i + j][tile][k] = (B^T d B)[i][j] of the tile's 6x6 patch (origin 4 ty - pad_top, 4 tx - pad_left), zero outside the map
-// and for k >= cin_pad.
+// V[c = 6 i + j][tile][v_c0 + k] = (B^T d B)[i][j] of the tile's 6x6 patch (origin 4 ty - pad_top, 4 tx - pad_left) for the channels
+// k in [0, kcount) of the layer's input window, zero outside the map and for k >= cin_pad.  Vp = row pitch of the slab: the layer's
+// own Kp (v_c0 = 0, kcount = Kp) in the self-contained form; the pitch of a DenseNet level's shared slab in the kept-slab form
+// (premvos_conv_wino4_slab_f32), where only the channels the previous layer added are transformed.
 __global__ __launch_bounds__(256) void wino4_input_kernel(const premvos_conv_desc p, float* __restrict__ V, const int tiles_y,
-                                                          const int tiles_x, const int Kp) {
-  const int Mt = p.n * tiles_y * tiles_x, kg = Kp / 4, tpi = tiles_y * tiles_x;
-  const long total = (long)Mt * kg, cstride = (long)Mt * Kp;
+                                                          const int tiles_x, const int Vp, const int v_c0, const int kcount) {
+  const int Mt = p.n * tiles_y * tiles_x, kg = kcount / 4, tpi = tiles_y * tiles_x;
+  const long total = (long)Mt * kg, cstride = (long)Mt * Vp;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int m = (int)(idx / kg), k = (int)(idx - (long)m * kg) * 4;
     const int n = m / tpi, rem = m - n * tpi;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const premvos_conv_des
       }
       bt6(d[0], d[1], d[2], d[3], d[4], d[5], t[b]);
     }
-    float* dst = V + (long)m * Kp + k;
+    float* dst = V + (long)m * Vp + v_c0 + k;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       float4 v[6];
@@ -82,11 +84,12 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const premvos_conv_des
   }
 }
 
-// M[c][tile][col] = sum_k V[c][tile][k] * U[c][col][k]; rows past Mt / cout_pad are computed on clamped addresses and never read.
+// M[c][tile][col] = sum_k V[c][tile][v_c0 + k] * U[c][col][k]; rows past Mt / cout_pad are computed on clamped addresses and never
+// read.  Vp = row pitch of V (Kp, or a shared slab's pitch with the layer's window at channel v_c0).
 template <int BM, int BN, int WM, int WN, int KB>
 __global__ __launch_bounds__(256) void wino4_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U,
                                                             float* __restrict__ Ms, const int Mt, const int Kp, const int cout_pad,
-                                                            const int m_tiles, const int n_tiles) {
+                                                            const int m_tiles, const int n_tiles, const int Vp, const int v_c0) {
   constexpr int NT = 256, RS = KB + 4, KU = KB / 4;
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void wino4_gemm_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
     const int m = min(m0 + (tid / KU) + i * (NT / KU), Mt - 1);
-    arow[i] = V + ((long)comp * Mt + m) * Kp + j4;
+    arow[i] = V + ((long)comp * Mt + m) * Vp + v_c0 + j4;
   }
 #pragma unroll
   for (int i = 0; i < B_PER_T; ++i) {
@@ -353,7 +356,7 @@ inline Geo geometry(const premvos_conv_desc& d) {
 }
 
 template <int BM, int BN, int WM, int WN, int KB>
-int launch_gemm(const premvos_conv_desc& d, const Geo& g, const float* V, float* Ms, hipStream_t s) {
+int launch_gemm(const premvos_conv_desc& d, const Geo& g, const float* V, const int Vp, const int v_c0, float* Ms, hipStream_t s) {
   const int m_tiles = premvos::cdiv((int)g.mt, BM);
   constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float);
   static const bool attr_done = [] {
@@ -363,7 +366,7 @@ int launch_gemm(const premvos_conv_desc& d, const Geo& g, const float* V, float*
   }();
   (void)attr_done;
   hipLaunchKernelGGL((wino4_gemm_kernel<BM, BN, WM, WN, KB>), dim3(36 * m_tiles * g.n_tiles), dim3(256), LDS_BYTES, s, V, d.wgt_wino4, Ms,
-                     (int)g.mt, g.kp, (int)d.cout_pad, m_tiles, g.n_tiles);
+                     (int)g.mt, g.kp, (int)d.cout_pad, m_tiles, g.n_tiles, Vp, v_c0);
   return premvos::check_launch("wino4_gemm");
 }
 
@@ -382,19 +385,21 @@ long conv_wino4_workspace_bytes(const premvos_conv_desc& d) {
   return 36L * g.mt * ((long)g.kp + (long)g.n_tiles * g.bn) * (long)sizeof(float);
 }
 
-// tile_hint 4; stage_k picks the GEMM block: 0 / 64 / 16 / 80
-int conv_wino4(const premvos_conv_desc& d, hipStream_t s) {
+long conv_wino4_m_bytes(const premvos_conv_desc& d) {
   const Geo g = geometry(d);
-  if (d.workspace == nullptr || d.workspace_bytes < conv_wino4_workspace_bytes(d))
-    return fail(PREMVOS_EINVAL, "conv2d(winograd 4x4): needs %ld workspace bytes", conv_wino4_workspace_bytes(d));
+  return 36L * g.mt * (long)g.n_tiles * g.bn * (long)sizeof(float);
+}
+
+// The three launches.  V: slab of pitch Vp with the layer's window at channel v_c0; channels [0, t_cn) of the window are
+// transformed now (the rest of [0, kp) is already there); Ms: 36 x tiles x (n_tiles x bn) floats.
+static int wino4_run(const premvos_conv_desc& d, const Geo& g, float* V, const int Vp, const int v_c0, const int t_cn, float* Ms,
+                     hipStream_t s) {
   if (g.mt >= (1L << 26)) return fail(PREMVOS_EINVAL, "conv2d(winograd 4x4): too many tiles");
   if (d.stage_k & ~(64 | 16)) return fail(PREMVOS_EINVAL, "conv2d(winograd 4x4): stage_k %d is not a block id (0, 16, 64, 80)", d.stage_k);
-  float* V = d.workspace;
-  float* Ms = d.workspace + 36L * g.mt * g.kp;
-  {
-    const long total = g.mt * (g.kp / 4);
+  if (t_cn > 0) {
+    const long total = g.mt * (t_cn / 4);
     const int grid = (int)(total / 256 < 1 ? 1 : total / 256 > (1 << 20) ? (1 << 20) : (total + 255) / 256);
-    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid), dim3(256), 0, s, d, V, g.ty, g.tx, g.kp);
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid), dim3(256), 0, s, d, V, g.ty, g.tx, Vp, v_c0, t_cn);
     const int rc = check_launch("wino4_input");
     if (rc) return rc;
   }
@@ -403,11 +408,11 @@ int conv_wino4(const premvos_conv_desc& d, hipStream_t s) {
   const bool bm64 = (d.stage_k & 64) != 0, k32 = g.kp % 32 == 0 && (d.stage_k & 16) == 0;
   int rc;
   if (g.bn == 64) {
-    rc = bm64 ? (k32 ? launch_gemm<64, 64, 2, 2, 32>(d, g, V, Ms, s) : launch_gemm<64, 64, 2, 2, 16>(d, g, V, Ms, s))
-              : (k32 ? launch_gemm<128, 64, 2, 2, 32>(d, g, V, Ms, s) : launch_gemm<128, 64, 2, 2, 16>(d, g, V, Ms, s));
+    rc = bm64 ? (k32 ? launch_gemm<64, 64, 2, 2, 32>(d, g, V, Vp, v_c0, Ms, s) : launch_gemm<64, 64, 2, 2, 16>(d, g, V, Vp, v_c0, Ms, s))
+              : (k32 ? launch_gemm<128, 64, 2, 2, 32>(d, g, V, Vp, v_c0, Ms, s) : launch_gemm<128, 64, 2, 2, 16>(d, g, V, Vp, v_c0, Ms, s));
   } else {
-    rc = bm64 ? (k32 ? launch_gemm<64, 128, 2, 2, 32>(d, g, V, Ms, s) : launch_gemm<64, 128, 2, 2, 16>(d, g, V, Ms, s))
-              : (k32 ? launch_gemm<128, 128, 2, 2, 32>(d, g, V, Ms, s) : launch_gemm<128, 128, 2, 2, 16>(d, g, V, Ms, s));
+    rc = bm64 ? (k32 ? launch_gemm<64, 128, 2, 2, 32>(d, g, V, Vp, v_c0, Ms, s) : launch_gemm<64, 128, 2, 2, 16>(d, g, V, Vp, v_c0, Ms, s))
+              : (k32 ? launch_gemm<128, 128, 2, 2, 32>(d, g, V, Vp, v_c0, Ms, s) : launch_gemm<128, 128, 2, 2, 16>(d, g, V, Vp, v_c0, Ms, s));
   }
   if (rc) return rc;
   const long total = g.mt * (d.cout / 4);
@@ -422,4 +427,37 @@ int conv_wino4(const premvos_conv_desc& d, hipStream_t s) {
   return check_launch("wino4_output");
 }
 
+// tile_hint 4; stage_k picks the GEMM block: 0 / 64 / 16 / 80.  Self-contained form: V and M slabs in the layer's workspace.
+int conv_wino4(const premvos_conv_desc& d, hipStream_t s) {
+  const Geo g = geometry(d);
+  if (d.workspace == nullptr || d.workspace_bytes < conv_wino4_workspace_bytes(d))
+    return fail(PREMVOS_EINVAL, "conv2d(winograd 4x4): needs %ld workspace bytes", conv_wino4_workspace_bytes(d));
+  return wino4_run(d, g, d.workspace, g.kp, 0, g.kp, d.workspace + 36L * g.mt * g.kp, s);
+}
+
 }  // namespace premvos
+
+// Kept-slab form for DenseNet blocks (PWCNet.py:201-264: layer i reads the concat of everything layers 0 ... i-1 produced, so
+// the self-contained form re-transforms the same channels up to four times).  The caller owns one V slab per concat buffer:
+// V[36][tiles][v_pitch], slab channel = channel of the concat buffer.  This layer's input window starts at slab channel v_c0;
+// channels [0, t_cn) of the window are transformed by this call (0 = everything it reads is already in the slab), the GEMM reads
+// [v_c0, v_c0 + Kp) with Kp = cin_pad rounded up to 16 -- the caller keeps [cin_pad, Kp) zero by transforming them once
+// (t_cn = Kp on the first layer of a level zero-fills them: every window of a level ends at the same channel).  Same V values,
+// same GEMM, same output transform as premvos_conv2d_f32 with tile_hint 4: bit-identical results.  d->workspace holds the M slab.
+extern "C" int premvos_conv_wino4_slab_f32(const premvos_conv_desc* dp, float* vslab, int64_t vslab_bytes, int32_t v_pitch, int32_t v_c0,
+                                          int32_t t_cn, void* stream) {
+  using namespace premvos;
+  if (dp == nullptr || vslab == nullptr) return fail(PREMVOS_EINVAL, "conv_wino4_slab: null argument");
+  const premvos_conv_desc& d = *dp;
+  if (const int rc = conv_desc_check(d)) return rc;
+  if (!conv_wino4_applicable(d)) return fail(PREMVOS_EINVAL, "conv_wino4_slab: the layer is not a 3x3 / stride-1 fp32 layer with F(4x4) weights");
+  const Geo g = geometry(d);
+  if ((v_pitch & 3) || (v_c0 & 3) || (t_cn & 3) || v_c0 < 0 || t_cn < 0 || t_cn > g.kp || v_c0 + g.kp > v_pitch || !aligned16(vslab))
+    return fail(PREMVOS_EINVAL, "conv_wino4_slab: window [%d, +%d) / transform count %d do not fit a slab of pitch %d (multiples of 4)", v_c0,
+                g.kp, t_cn, v_pitch);
+  if (vslab_bytes < 36L * g.mt * v_pitch * (long)sizeof(float))
+    return fail(PREMVOS_EINVAL, "conv_wino4_slab: slab of %ld bytes, needs %ld", (long)vslab_bytes, 36L * g.mt * v_pitch * (long)sizeof(float));
+  if (d.workspace == nullptr || d.workspace_bytes < conv_wino4_m_bytes(d))
+    return fail(PREMVOS_EINVAL, "conv_wino4_slab: needs %ld workspace bytes for the M slab", conv_wino4_m_bytes(d));
+  return wino4_run(d, g, vslab, v_pitch, v_c0, t_cn, d.workspace, static_cast<hipStream_t>(stream));
+}

@@ -59,6 +59,7 @@ class _Plan:
 
         self.flops: Dict[str, float] = {}   # algorithmic FLOPs (2*MAC, true cin/cout) per conv launch
         self.descs: List = []
+        dense: Dict[int, List] = {}         # estimator level -> [(step index, desc, first channel of the window in the level's buffer)]
 
         def conv(x, name, out, **kw):
             pk = P[name]
@@ -124,6 +125,7 @@ class _Plan:
             for i, g in enumerate(GROWTH):
                 xin = X.slice(off, GROW_SUM + od - off)
                 conv(xin, f"conv{lvl}_{i}", X.slice(off - g, g), pad=(1, 1), act=ACT_LEAKY)
+                dense.setdefault(lvl, []).append((len(steps) - 1, self.descs[-1], off))
                 off -= g
             flow = alloc(b, lh, lw, 2, dev)               # ps = 4 (pad lanes stay zero)
             self.level_flow[lvl] = flow
@@ -150,6 +152,27 @@ class _Plan:
         self.steps = steps
         self.buffers = keep
         self.ws = ops.assign_workspace(ops.autotune(self.descs, dev) or self.descs, dev)      # split-K scratch shared by the whole launch list
+        # Kept Winograd slabs (round 4): the F(4x4) layers of an estimator level transform only the channels the previous layer
+        # added to the level's concat buffer (PWCNet.py:201-205 prepends them); one slab, reused level after level.  Same bits.
+        self.vslab, self.vslab_layers = None, {}
+        if ops.vslab_enabled():
+            plans = {}
+            for lvl, lst in dense.items():
+                first = next((k for k, (_, d, _) in enumerate(lst) if d.tile_hint == 4), None)
+                if first is None:
+                    continue
+                run = [e for e in lst[first:]]
+                stop = next((k for k, (_, d, _) in enumerate(run) if d.tile_hint != 4), len(run))      # a consecutive run of F(4x4) layers
+                if stop >= 2:
+                    pl = ops.wino4_slab_plan([(d, off) for _, d, off in run[:stop]], dev)
+                    if pl is not None:
+                        plans[lvl] = (run[:stop], pl)
+            if plans:
+                self.vslab = torch.empty(max(pl[0] for _, pl in plans.values()), dtype=torch.float32, device=dev)
+                for lvl, (run, (_, plan)) in plans.items():
+                    for (idx, _, _), (d, pitch, c0, t_cn) in zip(run, plan):
+                        steps[idx] = (steps[idx][0], lambda d=d, p=pitch, c=c0, t=t_cn: ops.run_wino4_slab(d, self.vslab, p, c, t))
+                        self.vslab_layers[steps[idx][0]] = (c0, t_cn)
         self.feats, self.xbufs = feats, xbufs
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 

@@ -780,6 +780,38 @@ def run_desc(d: ConvDesc, stream: Optional[int] = None):
                "conv2d")
 
 
+def vslab_enabled() -> bool:
+    """PREMVOS_VSLAB=0: every F(4x4) layer of a DenseNet block transforms its whole input again (rounds 2-3)."""
+    return os.environ.get("PREMVOS_VSLAB", "1") != "0"
+
+
+def wino4_slab_plan(layers, device="cuda"):
+    """Kept input-transform slab for the Winograd F(4x4,3x3) layers of ONE DenseNet concat buffer (PWCNet.py:201-264: layer i
+    reads everything layers 0 ... i-1 produced; include/premvos_hip.h, premvos_conv_wino4_slab_f32).  ``layers``: (desc, first
+    channel of the layer's input window in the buffer) in launch order, every desc with tile_hint 4; the windows must start at
+    multiples of 16 and end at the same channel (then the zero K-padding the first layer writes serves all).  Returns
+    (floats of slab needed, [(desc, v_pitch, v_c0, t_cn)]) or None when the block does not have that shape."""
+    if not layers:
+        return None
+    ends = {off + d.cin for d, off in layers}
+    tiles = {d.n * ((d.ho + 3) // 4) * ((d.wo + 3) // 4) for d, _ in layers}
+    if len(ends) != 1 or len(tiles) != 1 or any(off % 16 or d.tile_hint != 4 for d, off in layers):
+        return None
+    kp = lambda d: _r(d.cin_pad, 16)
+    pitch = max(off + kp(d) for d, off in layers)
+    plan, lo = [], None
+    for d, off in layers:
+        t_cn = kp(d) if lo is None else max(0, lo - off)          # first layer: the whole window incl. the zero K padding
+        lo = off if lo is None else min(lo, off)
+        plan.append((d, pitch, off, t_cn))
+    return 36 * tiles.pop() * pitch, plan
+
+
+def run_wino4_slab(d: ConvDesc, slab: torch.Tensor, v_pitch: int, v_c0: int, t_cn: int, stream: Optional[int] = None):
+    _lib.check(_lib.load().premvos_conv_wino4_slab_f32(C.byref(d), slab.data_ptr(), slab.numel() * 4, v_pitch, v_c0, t_cn,
+                                                       _lib.current_stream() if stream is None else stream), "conv_wino4_slab")
+
+
 def corr(f1: NHWC, f2: NHWC, out: NHWC, md: int = 4, slope: float = 1.0, copy_f1: bool = False):
     assert (f1.n, f1.h, f1.w, f1.c) == (f2.n, f2.h, f2.w, f2.c)
     _lib.check(_lib.load().premvos_corr_fwd_f32(f1.ptr, f1.ps, f2.ptr, f2.ps, out.ptr, out.ps, f1.n, f1.h, f1.w,

@@ -141,3 +141,73 @@ def test_winograd_is_refused_where_it_does_not_apply():
         ops.conv2d(x, pk, out1, pad=(1, 1), tile_hint=3, stage_k=11)
     pk1 = ops.pack_conv(torch.randn((16, 16, 1, 1)), None)
     assert pk1.wgt_wino is None
+
+
+def test_kept_winograd_slab_of_a_densenet_block_is_bit_identical():
+    """premvos_conv_wino4_slab_f32: a PWC-Net estimator level in miniature (PWCNet.py:201-205: every layer prepends its output
+    to the concat buffer and the next layer reads the longer window).  Self-contained F(4x4) per layer against ONE kept slab in
+    which every layer transforms only the channels the previous one added: same bits, layer by layer."""
+    from premvos_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    n, h, w, od, growth = 2, 18, 27, 149, (128, 128, 96, 64)           # 149 = 81 + 64 + 4 channels under the grown ones (level 3)
+    total = sum(growth) + od
+    packs, off = [], sum(growth)
+    for gch in growth:
+        cin = total - off
+        packs.append((off, gch, ops.pack_conv(torch.randn((gch, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5,
+                                              torch.randn((gch,), generator=g) * 0.1)))
+        off -= gch
+    base = torch.randn((n, h, w, od), generator=g).cuda()
+
+    def fresh():
+        X = ops.NHWC.alloc(n, h, w, total)
+        X.buf.zero_()
+        X.buf[..., sum(growth):total] = base
+        return X
+
+    def descs(X):
+        ds = []
+        for off, gch, pk in packs:
+            d = ops.conv_desc(X.slice(off, total - off), pk, X.slice(off - gch, gch), pad=(1, 1), act=ops.ACT_LEAKY, tile_hint=4)
+            ds.append((d, off))
+        ws = ops.assign_workspace([d for d, _ in ds])
+        return ds, ws
+
+    Xa = fresh()
+    da, wsa = descs(Xa)
+    for d, _ in da:
+        ops.run_desc(d)
+    Xb = fresh()
+    db, wsb = descs(Xb)
+    need, plan = ops.wino4_slab_plan(db)
+    assert [(c0, t) for _, _, c0, t in plan] == [(416, 160), (288, 128), (160, 128), (64, 96)]       # first: its whole Kp = 160
+    assert plan[0][1] == 576 and need == 36 * n * 5 * 7 * 576                      # pitch: the buffer's 565 channels rounded to 16
+    slab = torch.full((need,), float("nan"), device="cuda")                         # nothing stale may be read
+    for d, pitch, c0, t_cn in plan:
+        ops.run_wino4_slab(d, slab, pitch, c0, t_cn)
+    torch.cuda.synchronize()
+    assert torch.equal(Xa.buf, Xb.buf) and bool(torch.isfinite(Xb.buf).all())
+    # a second pass over the same slab (a replayed launch list) and t_cn = 0 (everything already there): same bits again
+    Xb.buf[..., :sum(growth)].zero_()
+    for d, pitch, c0, t_cn in plan:
+        ops.run_wino4_slab(d, slab, pitch, c0, t_cn)
+    d3, pitch, c0, _ = plan[3]
+    ops.run_wino4_slab(d3, slab, pitch, c0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(Xa.buf, Xb.buf)
+    # what the entry point refuses
+    d0 = plan[0][0]
+    with pytest.raises(_lib.PremvosError, match="do not fit"):
+        ops.run_wino4_slab(d0, slab, 560, 416, 128)                                 # window end beyond the pitch
+    with pytest.raises(_lib.PremvosError, match="do not fit"):
+        ops.run_wino4_slab(d0, slab, 576, 414, 128)                                 # not a multiple of 4
+    with pytest.raises(_lib.PremvosError, match="needs"):
+        ops.run_wino4_slab(d0, slab[:1000], 576, 416, 128)
+    pk1 = ops.pack_conv(torch.randn((16, 16, 3, 3)), None)
+    x1 = ops.NHWC.alloc(1, 8, 8, 16)
+    d1 = ops.conv_desc(x1, pk1, ops.NHWC.alloc(1, 8, 8, 16), pad=(1, 1))
+    with pytest.raises(_lib.PremvosError, match="not a 3x3"):
+        ops.run_wino4_slab(d1, slab, 16, 0, 16)
+    # a block whose windows do not start at multiples of 16 gets no plan (the layers then run self-contained)
+    assert ops.wino4_slab_plan([(db[0][0], 321), (db[1][0], 192)]) is None

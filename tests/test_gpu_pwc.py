@@ -108,3 +108,27 @@ def test_flow_stage_pre_post_and_end_to_end(h, w, tmp_path):
     writeFlowFile(fn, got[0])
     assert np.array_equal(readFlowFile(fn), got[0])
     assert _lib.lib_path().endswith("libpremvos_hip.so")
+
+
+def test_kept_winograd_slabs_leave_the_flow_bit_identical(monkeypatch):
+    """The bench's flow shape (16 pairs at 512x896, the shipped table's choices): the F(4x4) layers of the estimator levels keep one
+    input-transform slab per level and transform only the channels the previous layer added (PWCNet.py:201-205) -- the flow and
+    every level's concat buffer are bit-identical to the plan in which each layer transforms its whole window again."""
+    x = torch.cat([O.synth_frame_pair(512, 896, seed=20 + i, shift=(1.5 * i - 3.0, 0.75 * i)) for i in range(4)], 0).cuda()
+    x = x.repeat(4, 1, 1, 1)
+    monkeypatch.setenv("PREMVOS_VSLAB", "0")
+    net0 = _net(11, False)
+    f0 = net0(x)
+    p0 = net0.plan(16, 512, 896)
+    assert p0.vslab is None and not p0.vslab_layers
+    monkeypatch.setenv("PREMVOS_VSLAB", "1")
+    net1 = _net(11, False)
+    f1 = net1(x)
+    p1 = net1.plan(16, 512, 896)
+    torch.cuda.synchronize()
+    kept = p1.vslab_layers
+    assert len(kept) >= 8, kept                                          # levels 5 ... 2: three or four F(4x4) layers each
+    assert kept["conv:conv3_1"] == (320, 128) and kept["conv:conv3_3"] == (96, 96) and kept["conv:conv2_2"] == (192, 128)
+    assert torch.equal(f0, f1)
+    for lvl in (5, 4, 3, 2):
+        assert torch.equal(p0.xbufs[lvl].buf, p1.xbufs[lvl].buf), lvl
