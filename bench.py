@@ -208,6 +208,8 @@ def file_to_file(n_frames: int, chunk: int):
         return {"streaming_driver_fps": round(n_frames / min(times[1:]), 2), "cold_run_s": round(times[0], 1),
                 "warm_runs_s": [round(t, 2) for t in times[1:]], "frames": n_frames, "chunk": chunk,
                 "proposals_per_frame": round(props / n_frames, 1), "files_written": files, "n_gpus": 1, "measured_by_this_run": True,
+                "cold_start_overhead_s": round(times[0] - min(times[1:]), 2),          # plans, buffers, first launches: cold minus warm
+                "hbm_resident_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),      # this process: bench pipeline + the driver's plans
                 "what": "python -m premvos_amd.stream's pipeline object on a synthetic 480x854 JPEG sequence (quality 95): decode -> flow + "
                         "proposals x2 + combine + refinement -> .flo / JSON / COCO-RLE files; `value` above stays the HBM-resident metric"}
     finally:
