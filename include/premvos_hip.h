@@ -283,7 +283,10 @@ int premvos_dwconv3x3_f32(const float* in, int32_t in_ps, int32_t n, int32_t h, 
  * Outputs, each optional (at least one): d->out (fp32 NHWC, d->out_ps) and out_s8 (S8, pixel stride out_s8_ps floats' worth) =
  * act(sum + d->bias (+ d->res, fp32 -- or res_s8, the residual in S8 with pixel stride res_s8_ps: hi + lo, so that a bottleneck
  * chain needs no fp32 copy of its block outputs)); cout % 8 == 0.  tile: 0 = 256x256 / 8 waves / 2 buffers, 1 = 256x128 / 4 waves / 3 buffers,
- * 2 = 256x128 / 4 waves / 2 buffers, 3 = 256x128 / 8 waves / 3 buffers, 4 = 128x128 / 4 waves / 3 buffers, 5 = 128x128 / 2 buffers. */
+ * 2 = 256x128 / 4 waves / 2 buffers, 3 = 256x128 / 8 waves / 3 buffers, 4 = 128x128 / 4 waves / 3 buffers, 5 = 128x128 / 2 buffers,
+ * 6 / 7 = 256x128 and 8 = 128x256 on 16-channel stages (two workgroups per CU), 9 = 256x64, 10 = 256x256 ping-pong wave groups
+ * (pointwise layers), 11 = 256x256 / 4 waves of 128x128.  Every tile adds an output's products in the same order: bit-identical
+ * results -- the tile is a speed knob only (premvos_amd.ops.s8_tile_rule picks 0 or 5; the others are measured alternatives). */
 int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* d, const void* in_s8, const void* wgt_s8, void* out_s8,
                                int32_t out_s8_ps, const void* res_s8, int32_t res_s8_ps, int32_t tile, void* stream);
 

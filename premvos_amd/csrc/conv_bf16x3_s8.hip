@@ -595,6 +595,7 @@ extern "C" int premvos_conv_bf16x3_s8_f32(const premvos_conv_desc* dp, const voi
       const bool padded = a.cout_pad % 256 == 0;         // (ops.pack_conv_s8 pads the weight rows to whole 256-row tiles)
       return pw && small && padded ? launch_pp(a, s) : launch<256, 256, 2, 4, 2>(a, s);
     }
+    case 11: return launch<256, 256, 2, 2, 2>(a, s);      // four waves of 128 x 128 (one per SIMD, 256 accumulator registers): 16 fragment reads per 48 MFMAs
     default: return premvos::fail(PREMVOS_EINVAL, "conv_bf16x3_s8: unknown tile %d", tile);
   }
 }

@@ -43,7 +43,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", list(range(11)))
+@pytest.mark.parametrize("tile", list(range(12)))
 def test_conv_s8_matches_the_fp64_convolution(case, tile):
     ops = _ops()
     cin, cout, k, stride, dil, pad, n, h, w, res, act = case
@@ -98,7 +98,7 @@ def test_conv_s8_tiles_are_bit_identical_and_chain():
     w3 = torch.randn((256, 64, 1, 1), generator=g) * (1.0 / 64) ** 0.5
     xin = _to_s8(x, ops)
     outs = []
-    for tile in range(11):
+    for tile in range(12):
         o = ops.NHWC.alloc(2, 19, 27, 64)
         ops.conv_s8(xin, ops.pack_conv_s8(w1, None), o, None, tile=tile, act=ops.ACT_RELU)
         torch.cuda.synchronize()
