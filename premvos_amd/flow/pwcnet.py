@@ -158,15 +158,15 @@ class _Plan:
         if ops.vslab_enabled():
             plans = {}
             for lvl, lst in dense.items():
-                first = next((k for k, (_, d, _) in enumerate(lst) if d.tile_hint == 4), None)
-                if first is None:
+                hints = [d.tile_hint == 4 for _, d, _ in lst]
+                if True not in hints:
                     continue
-                run = [e for e in lst[first:]]
-                stop = next((k for k, (_, d, _) in enumerate(run) if d.tile_hint != 4), len(run))      # a consecutive run of F(4x4) layers
-                if stop >= 2:
-                    pl = ops.wino4_slab_plan([(d, off) for _, d, off in run[:stop]], dev)
+                first = hints.index(True)
+                stop = hints.index(False, first) if False in hints[first:] else len(lst)         # the first consecutive run of F(4x4) layers
+                if stop - first >= 2:                                                            # (a single layer has nothing to share)
+                    pl = ops.wino4_slab_plan([(d, off) for _, d, off in lst[first:stop]])
                     if pl is not None:
-                        plans[lvl] = (run[:stop], pl)
+                        plans[lvl] = (lst[first:stop], pl)
             if plans:
                 self.vslab = torch.empty(max(pl[0] for _, pl in plans.values()), dtype=torch.float32, device=dev)
                 for lvl, (run, (_, plan)) in plans.items():

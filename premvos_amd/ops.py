@@ -785,7 +785,7 @@ def vslab_enabled() -> bool:
     return os.environ.get("PREMVOS_VSLAB", "1") != "0"
 
 
-def wino4_slab_plan(layers, device="cuda"):
+def wino4_slab_plan(layers):
     """Kept input-transform slab for the Winograd F(4x4,3x3) layers of ONE DenseNet concat buffer (PWCNet.py:201-264: layer i
     reads everything layers 0 ... i-1 produced; include/premvos_hip.h, premvos_conv_wino4_slab_f32).  ``layers``: (desc, first
     channel of the layer's input window in the buffer) in launch order, every desc with tile_hint 4; the windows must start at

@@ -64,3 +64,29 @@ def test_numerics_key_separates_what_changes_the_summation_order():
     assert ops.numerics_key(d, (t128, 16, 4, 0, 0)) != ops.numerics_key(d, (t128, 16, 2, 0, 0))
     assert ops.numerics_key(d, (t128, 16, -1, 3, 4)) != ops.numerics_key(d, (t128, 16, -1, 0, 0))         # a tail split re-orders its rows
     assert ops.numerics_key(d, (2, 0, -1, 0, 0)) == ops.numerics_key(d, (2, 64, -1, 0, 0)) != ops.numerics_key(d, (3, 0, -1, 0, 0))
+
+
+def test_kept_winograd_slab_plan_of_a_densenet_level():
+    """ops.wino4_slab_plan (host logic only): PWC-Net level 3's F(4x4) layers -- windows [448, 597), [320, 597), [192, 597),
+    [96, 597) of one concat buffer (PWCNet.py:201-205) -- share a slab of pitch 608; the first transforms its whole Kp, the others
+    only what the previous layer prepended.  Shapes the shared zero padding would not cover get no plan."""
+    from premvos_amd import ops
+    from premvos_amd._lib import ConvDesc
+
+    def desc(off, hint=4, end=597, n=16, h=64, w=112):
+        d = ConvDesc()
+        d.n, d.h, d.w, d.ho, d.wo, d.cin, d.tile_hint = n, h, w, h, w, end - off, hint
+        d.cin_pad = (d.cin + 3) // 4 * 4
+        return d, off
+
+    need, plan = ops.wino4_slab_plan([desc(448), desc(320), desc(192), desc(96)])
+    assert [(c0, t) for _, _, c0, t in plan] == [(448, 160), (320, 128), (192, 128), (96, 96)]
+    assert {p for _, p, _, _ in plan} == {608} and need == 36 * 16 * 16 * 28 * 608
+    assert ops.wino4_slab_plan([desc(448), desc(320, hint=2)]) is None            # a layer on another kernel
+    assert ops.wino4_slab_plan([desc(448), desc(324)]) is None                    # window not at a multiple of 16
+    assert ops.wino4_slab_plan([desc(448), desc(320, end=600)]) is None           # windows that end at different channels
+    assert ops.wino4_slab_plan([desc(448), desc(320, h=32)]) is None              # different maps
+    assert ops.wino4_slab_plan([]) is None
+    # a later layer whose window starts ABOVE what is already in the slab transforms nothing
+    _, plan = ops.wino4_slab_plan([desc(320), desc(448)])
+    assert [(c0, t) for _, _, c0, t in plan] == [(320, 288), (448, 0)]
