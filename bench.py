@@ -192,6 +192,9 @@ def file_to_file(n_frames: int, chunk: int):
         torch.save(synth.proposal_weights(1), os.path.join(wd, "specific.pt"))
         torch.save(synth.refinement_weights(0), os.path.join(wd, "refine.pt"))
         out = os.path.join(root, "output", "intermediate")
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()                   # the bench's own pipeline object, still alive
         sp = stream.StreamPipeline(os.path.join(wd, "pwc.pth.tar"), os.path.join(wd, "general.pt"), os.path.join(wd, "specific.pt"),
                                    os.path.join(wd, "refine.pt"), batch=chunk, out=out)
         times = []
@@ -209,7 +212,8 @@ def file_to_file(n_frames: int, chunk: int):
                 "warm_runs_s": [round(t, 2) for t in times[1:]], "frames": n_frames, "chunk": chunk,
                 "proposals_per_frame": round(props / n_frames, 1), "files_written": files, "n_gpus": 1, "measured_by_this_run": True,
                 "cold_start_overhead_s": round(times[0] - min(times[1:]), 2),          # plans, buffers, first launches: cold minus warm
-                "hbm_resident_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),      # this process: bench pipeline + the driver's plans
+                "hbm_resident_gb": round((torch.cuda.max_memory_allocated() - base) / 2 ** 30, 1),      # peak of the driver's own plans, weights and buffers
+                "hbm_process_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),                # ... on top of the bench's pipeline object
                 "what": "python -m premvos_amd.stream's pipeline object on a synthetic 480x854 JPEG sequence (quality 95): decode -> flow + "
                         "proposals x2 + combine + refinement -> .flo / JSON / COCO-RLE files; `value` above stays the HBM-resident metric"}
     finally:

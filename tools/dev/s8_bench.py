@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from premvos_amd import ops, _lib
 import ctypes as C
 lib, st = _lib.load(), _lib.current_stream()
-TILES = [int(t) for t in os.environ.get("S8_TILES", "0,1,2,3,4,5,6,7,8,9,10").split(",")]
+TILES = [int(t) for t in os.environ.get("S8_TILES", "0,1,2,3,4,5,6,7,8,9,10,11").split(",")]
 
 
 def timeit(fn, reps=10):
