@@ -435,3 +435,43 @@ def test_streaming_pointwise_kernel_is_bit_identical_to_the_implicit_gemm(cin, c
     assert not ops.stream_applicable(d)
     with pytest.raises(_lib.PremvosError, match="streaming pointwise"):
         ops.run_desc(d)
+
+
+@pytest.mark.parametrize("n,cin,h,w,res", [(2, 597, 64, 112, False), (3, 117, 45, 53, True), (1, 32, 128, 224, True), (2, 565, 16, 28, False)])
+def test_two_channel_heads_tiled_form_matches_the_per_pixel_form_and_fp64(n, cin, h, w, res):
+    """PWC-Net's predict_flow / dc_conv7 heads (PWCNet.py:131, 267: 3x3, two outputs) on csrc/conv_smalln_f32.hip: maps of >= 100
+    4x4 tiles take the tiled form (every loaded pixel feeds its nine outputs), smaller ones the per-pixel form (stage_k = 1 forces
+    it).  Both against torch's fp64 convolution; the choice depends on the map, never on the batch -- image 0 of a batch of n has
+    the bits of a batch of one (a ragged last chunk must not change a frame's numbers)."""
+    from premvos_amd import ops
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((2, cin, 3, 3), generator=g) * (1.0 / (9 * cin)) ** 0.5
+    b = torch.randn((2,), generator=g)
+    r = torch.randn((n, 2, h, w), generator=g) if res else None
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    if res:
+        ref = ref + r.double()
+
+    def nhwc(t, ps=None):
+        v = ops.NHWC.alloc(t.shape[0], t.shape[2], t.shape[3], ps or t.shape[1])
+        v.buf.zero_()
+        v.buf[..., :t.shape[1]] = t.permute(0, 2, 3, 1).cuda()
+        return v.slice(0, t.shape[1])
+
+    pk = ops.pack_conv(wt, b)
+    xin, rin = nhwc(x), (nhwc(r, 4) if res else None)
+    got = {}
+    for sk in (0, 1):
+        out = ops.NHWC.alloc(n, h, w, 2)
+        out.buf.fill_(5.0)
+        ops.conv2d(xin, pk, out, pad=(1, 1), res=rin, tile_hint=1, stage_k=sk)
+        torch.cuda.synchronize()
+        got[sk] = out.torch().cpu()
+        assert (got[sk].double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), sk
+    tiled = ((h + 3) // 4) * ((w + 3) // 4) >= 100
+    assert torch.equal(got[0], got[1]) == (not tiled)              # below the threshold both calls ARE the per-pixel form
+    one = ops.NHWC.alloc(1, h, w, 2)
+    ops.conv2d(nhwc(x[:1]), pk, one, pad=(1, 1), res=nhwc(r[:1], 4) if res else None, tile_hint=1)
+    torch.cuda.synchronize()
+    assert torch.equal(one.torch().cpu()[0], got[0][0])
