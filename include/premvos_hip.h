@@ -103,6 +103,7 @@ typedef struct premvos_conv_desc {
   int32_t stage_k;      /* fp32 path: k depth of an LDS stage, 16 or 32 (0 = library default); with tile_hint == 2: 64 = 64 */
                         /* instead of 128 tile rows per workgroup; with tile_hint == 3: the block (2x2-tile rows x      */
                         /* couts / waves / stage depth) of a workgroup: 0, 2..6 (table in csrc/conv_wino_f32.hip)       */
+                        /* with tile_hint == 0 / 1 on a 1-2 channel head: 1 = keep the per-pixel form (csrc/conv_smalln_f32.hip) */
   const void* wgt_lo;   /* BF16X3: bf16 low parts (w - float(hi)), same shape as wgt */
   int32_t tail_m_tiles; /* fp32 path, unsplit layers: the last tail_m_tiles rows of BM-tall output tiles are computed  */
   int32_t tail_split_k; /* as tail_split_k k-slices + fixed-order reduce (fills a partly empty last wave); 0 = off    */
