@@ -337,7 +337,13 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const premvos_conv_de
   }
 }
 
-inline int wino4_bn(const premvos_conv_desc& d) { return d.cout <= 64 ? 64 : 128; }
+// columns of a GEMM workgroup: 32 for the 32-cout estimator layers of PWC-Net (PWCNet.py:96-101 conv*_4; needs 32-deep stages: a
+// 32 x 16 weight stage is half a request per thread), else 64 / 128
+inline int wino4_bn(const premvos_conv_desc& d) {
+  const int kp = premvos::cdiv((int)d.cin_pad, 16) * 16;
+  if (d.cout <= 32 && kp % 32 == 0 && (d.stage_k & 16) == 0) return 32;
+  return d.cout <= 64 ? 64 : 128;
+}
 
 struct Geo {
   int ty, tx, kp, bn, n_tiles;
@@ -407,7 +413,9 @@ static int wino4_run(const premvos_conv_desc& d, const Geo& g, float* V, const i
   // instead of two workgroups per CU: the better trade for short K, where a tile's first loads and epilogue weigh most)
   const bool bm64 = (d.stage_k & 64) != 0, k32 = g.kp % 32 == 0 && (d.stage_k & 16) == 0;
   int rc;
-  if (g.bn == 64) {
+  if (g.bn == 32) {
+    rc = launch_gemm<128, 32, 4, 1, 32>(d, g, V, Vp, v_c0, Ms, s);      // (four waves of 32 x 32: the only block of this width)
+  } else if (g.bn == 64) {
     rc = bm64 ? (k32 ? launch_gemm<64, 64, 2, 2, 32>(d, g, V, Vp, v_c0, Ms, s) : launch_gemm<64, 64, 2, 2, 16>(d, g, V, Vp, v_c0, Ms, s))
               : (k32 ? launch_gemm<128, 64, 2, 2, 32>(d, g, V, Vp, v_c0, Ms, s) : launch_gemm<128, 64, 2, 2, 16>(d, g, V, Vp, v_c0, Ms, s));
   } else {

@@ -135,7 +135,7 @@ def wino_enabled() -> bool:
 
 
 WINO4_MAX_WS = 16 << 30     # bytes of workspace one layer may ask for
-WINO4_MIN_C, WINO4_MIN_COUT = 128, 64       # F(4x4,3x3) moves 2.25x the input and output through workspace slabs: only K- and N-rich layers gain
+WINO4_MIN_C, WINO4_MIN_COUT = 128, int(os.environ.get("PREMVOS_WINO4_MIN_COUT", "32"))       # F(4x4,3x3) moves 2.25x the input and output through workspace slabs: only K- and N-rich layers gain
 
 
 def wino4_enabled() -> bool:

@@ -85,7 +85,8 @@ def test_atrous_winograd_matches_torch(n, cin, cout, h, w, dil):
 
 @pytest.mark.parametrize("n,cin,cout,h,w,act,res", [(1, 256, 256, 46, 83, "relu", False), (2, 128, 128, 32, 40, "leaky", True),
                                                     (1, 1024, 1024, 12, 21, "relu", False), (3, 130, 132, 9, 5, "none", True),
-                                                    (5, 512, 512, 7, 7, "relu", True), (1, 160, 136, 4, 3, "relu", False), (2, 245, 64, 20, 36, "leaky", False)])
+                                                    (5, 512, 512, 7, 7, "relu", True), (1, 160, 136, 4, 3, "relu", False), (2, 245, 64, 20, 36, "leaky", False),
+                                                    (2, 533, 32, 20, 36, "leaky", False), (1, 520, 32, 9, 14, "leaky", True)])     # PWC conv*_4: 32-column GEMM block (Kp % 32 == 0) / 64
 def test_winograd_4x4_matches_torch(n, cin, cout, h, w, act, res):
     """F(4x4,3x3) (csrc/conv_wino4_f32.hip: input transform, 36 batched GEMMs, output transform; tile_hint 4) on K-rich layers:
     maps that are not multiples of the 4x4 tile, channel counts off the GEMM tiles, channel windows, fused epilogue."""
