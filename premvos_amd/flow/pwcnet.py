@@ -16,6 +16,7 @@ epilogue.  The whole forward is a fixed list of kernel launches built once per i
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -38,6 +39,9 @@ CONTEXT = (("dc_conv1", 128, 1), ("dc_conv2", 128, 2), ("dc_conv3", 128, 4), ("d
 
 def _od(level: int) -> int:
     return ND if level == 6 else ND + FEAT[level] + 4
+
+
+FLOW_WINO4_MIN_C = int(os.environ.get("PREMVOS_FLOW_WINO4_MIN_C", "64"))
 
 
 class _Plan:
@@ -230,7 +234,9 @@ class PWCDCNet:
             if key.startswith(("deconv", "upfeat")):
                 packed[key] = ops.pack_deconv4x4s2(w, bia, self.device, self.precision)
             else:
-                packed[key] = ops.pack_conv(w, bia, self.device, precision=self.precision)
+                # F(4x4,3x3) from 64 input channels here (the other nets: 128): conv2_0 757 -> 600 us, dc_conv6 407 -> 335, conv3aa / conv3b
+                # 167 -> 139 (tools/dev/cands_3x3.py); its ~1e-5 rounding is two orders below the flow's 1e-3 px bar
+                packed[key] = ops.pack_conv(w, bia, self.device, precision=self.precision, wino4_min_c=FLOW_WINO4_MIN_C)
         if strict:
             need = set()
             for lv in PYR.values():

@@ -91,7 +91,7 @@ def default_precision() -> str:
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
-              scale: Optional[torch.Tensor] = None, precision: str = "fp32") -> PackedConv:
+              scale: Optional[torch.Tensor] = None, precision: str = "fp32", wino4_min_c: Optional[int] = None) -> PackedConv:
     """OIHW fp32 -> [cout_pad][k_pad] with k = (kh*KW+kw)*cin_pad + c.  ``scale`` (per cout)
     folds a frozen BatchNorm's gamma/sqrt(var+eps) into the weights.  precision 'bf16' / 'bf16x3': the matrix
     is stored as bfloat16 high parts (+ low parts w - float(hi)) and k is padded to 32."""
@@ -116,7 +116,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
         pk = PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
         if (kh, kw) == (3, 3) and cout % 4 == 0 and cin >= WINO_MIN_CIN and wino_enabled():
             pk.wgt_wino = pack_winograd(w, cin_pad, cout_pad, device)
-            if cin >= WINO4_MIN_C and cout >= WINO4_MIN_COUT and wino4_enabled():
+            if cin >= (WINO4_MIN_C if wino4_min_c is None else wino4_min_c) and cout >= WINO4_MIN_COUT and wino4_enabled():
                 pk.wgt_wino4 = pack_winograd4(w, cin_pad, cout_pad, device)
         return pk
     hi = full.to(torch.bfloat16)
@@ -135,7 +135,7 @@ def wino_enabled() -> bool:
 
 
 WINO4_MAX_WS = 16 << 30     # bytes of workspace one layer may ask for
-WINO4_MIN_C, WINO4_MIN_COUT = 128, int(os.environ.get("PREMVOS_WINO4_MIN_COUT", "32"))       # F(4x4,3x3) moves 2.25x the input and output through workspace slabs: only K- and N-rich layers gain
+WINO4_MIN_C, WINO4_MIN_COUT = int(os.environ.get("PREMVOS_WINO4_MIN_C", "128")), int(os.environ.get("PREMVOS_WINO4_MIN_COUT", "32"))       # F(4x4,3x3) moves 2.25x the input and output through workspace slabs: only K- and N-rich layers gain
 
 
 def wino4_enabled() -> bool:
@@ -455,7 +455,7 @@ def rule_choice(d: ConvDesc):
     if 1 in fams:
         return (1, 0, -1, 0, 0)                                  # 1-2 channel heads: the direct kernel
     if 4 in fams and m >= 16384:
-        return (4, 0 if m >= 65536 else 64, -1, 0, 0)            # K-rich 3x3 (cin >= 128, cout >= 64 at pack time): F(4x4,3x3)
+        return (4, (0 if m >= 65536 else 64) + (16 if d.cin_pad < 512 else 0), -1, 0, 0)      # K-rich 3x3 (packed with F(4x4) filters): F(4x4,3x3); 16-deep stages for short K
     if 2 in fams and m < 8192:
         return (2, 64 if d.cout > 32 else 0, -1, 0, 0)           # coarse pyramid levels: too few blocks for the slab-free kernel
     if 3 in fams and d.cout > 32:
