@@ -94,6 +94,7 @@ typedef struct premvos_conv_desc {
                         /* workspace + an output-transform launch; 3 = the same algebra in ONE kernel without workspace */
                         /* (a workgroup walks all 16 components of its block; output transform from registers);         */
                         /* 4 = Winograd F(4x4,3x3) (needs wgt_wino4 + workspace): 4x fewer multiplies, for K-rich layers  */
+                        /*     (3x3 / stride 1; atrous layers with dilation d = pad run as d x d interleaved sub-lattices)      */
                         /* 5 = short-K pointwise layers (1x1, stride 1, cin = 64 | 128 = k_pad, cout % 128 == 0, <= 512):   */
                         /* persistent workgroups, weights resident in LDS (csrc/conv_stream_f32.hip); the implicit GEMM's sums */
   int32_t split_k;      /* 0 = auto, <0 = never, >0 = force this many k-slices */

@@ -886,7 +886,7 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
     return premvos::conv_wino(d, s);
   }
   if (d.tile_hint == 4) {      // Winograd F(4x4,3x3) for K-rich layers (input transform, 36 batched GEMMs, output transform)
-    PV_REQUIRE(premvos::conv_wino4_applicable(d), "conv2d: Winograd F(4x4,3x3) needs a 3x3 / stride 1 / dilation 1 fp32 layer with "
+    PV_REQUIRE(premvos::conv_wino4_applicable(d), "conv2d: Winograd F(4x4,3x3) needs a 3x3 / stride 1 fp32 layer (dilated: equal in both directions) with "
                "cout %% 4 == 0, symmetric padding and packed filter transforms (wgt_wino4)");
     return premvos::conv_wino4(d, s);
   }

@@ -52,26 +52,30 @@ __device__ __forceinline__ void bt6(const float4& d0, const float4& d1, const fl
 // (premvos_conv_wino4_slab_f32), where only the channels the previous layer added are transformed.
 __global__ __launch_bounds__(256) void wino4_input_kernel(const premvos_conv_desc p, float* __restrict__ V, const int tiles_y,
                                                           const int tiles_x, const int Vp, const int v_c0, const int kcount) {
-  const int Mt = p.n * tiles_y * tiles_x, kg = kcount / 4, tpi = tiles_y * tiles_x;
+  // atrous layers (dilation d = p.dh = p.dw, PWCNet.py:266 dc_conv2..5): the d x d interleaved sub-grids are independent dense 3x3
+  // problems -- tile (phase (py, px), ty, tx) covers outputs ((4 ty + a) d + py, (4 tx + b) d + px) and reads the inputs d apart
+  const int d = p.dh, tpp = tiles_y * tiles_x, tpi = d * d * tpp;
+  const int Mt = p.n * tpi, kg = kcount / 4;
   const long total = (long)Mt * kg, cstride = (long)Mt * Vp;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int m = (int)(idx / kg), k = (int)(idx - (long)m * kg) * 4;
     const int n = m / tpi, rem = m - n * tpi;
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int y0 = 4 * ty - p.pt, x0 = 4 * tx - p.pl;
+    const int ph = rem / tpp, tt = rem - ph * tpp;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int y0 = 4 * ty * d + ph / d - p.pt, x0 = 4 * tx * d + ph % d - p.pl;
     const bool kok = k < p.cin_pad;
     const float* img = p.in + (long)n * p.h * p.w * p.in_ps + k;
     float4 t[6][6];                                             // t[j][i] = (B^T d)[i][j]: the column pass, stored transposed
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-      float4 d[6];
+      float4 dd[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        const int y = y0 + a, x = x0 + b;
+        const int y = y0 + a * d, x = x0 + b * d;
         const bool ok = kok && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
-        d[a] = ok ? *reinterpret_cast<const float4*>(img + ((long)y * p.w + x) * p.in_ps) : f4(0.f);
+        dd[a] = ok ? *reinterpret_cast<const float4*>(img + ((long)y * p.w + x) * p.in_ps) : f4(0.f);
       }
-      bt6(d[0], d[1], d[2], d[3], d[4], d[5], t[b]);
+      bt6(dd[0], dd[1], dd[2], dd[3], dd[4], dd[5], t[b]);
     }
     float* dst = V + (long)m * Vp + v_c0 + k;
 #pragma unroll
@@ -281,7 +285,8 @@ __device__ __forceinline__ void at6(const float4& m0, const float4& m1, const fl
 template <bool WIDE>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const premvos_conv_desc p, const float* __restrict__ Ms, const int tiles_y,
                                                            const int tiles_x, const int ncols) {
-  const int Mt = p.n * tiles_y * tiles_x, c4 = p.cout / 4, tpi = tiles_y * tiles_x;
+  const int d = p.dh, tpp = tiles_y * tiles_x, tpi = d * d * tpp;
+  const int Mt = p.n * tpi, c4 = p.cout / 4;
   const long total = (long)Mt * c4, cstride = (long)Mt * ncols;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int m = (int)(idx / c4), col = (int)(idx - (long)m * c4) * 4;
@@ -295,17 +300,18 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const premvos_conv_de
       at6(mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], s[j]);
     }
     const int n = m / tpi, rem = m - n * tpi;
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int ph = rem / tpp, tt = rem - ph * tpp;
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
     const float4 bv = p.bias != nullptr ? *reinterpret_cast<const float4*>(p.bias + col) : f4(0.f);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       float4 y[4];
       at6(s[0][a], s[1][a], s[2][a], s[3][a], s[4][a], s[5][a], y);
-      const int oy = 4 * ty + a;
+      const int oy = (4 * ty + a) * d + ph / d;
       if (oy >= p.ho) continue;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int ox = 4 * tx + b;
+        const int ox = (4 * tx + b) * d + ph % d;
         if (ox >= p.wo) continue;
         const long pix = ((long)n * p.ho + oy) * p.wo + ox;
         float4 v = y[b] + bv;
@@ -352,9 +358,9 @@ struct Geo {
 
 inline Geo geometry(const premvos_conv_desc& d) {
   Geo g;
-  g.ty = (d.ho + 3) / 4;
-  g.tx = (d.wo + 3) / 4;
-  g.mt = (long)d.n * g.ty * g.tx;
+  g.ty = (premvos::cdiv((int)d.ho, (int)d.dh) + 3) / 4;      // per phase of an atrous layer (dilation 1: one phase)
+  g.tx = (premvos::cdiv((int)d.wo, (int)d.dw) + 3) / 4;
+  g.mt = (long)d.n * d.dh * d.dw * g.ty * g.tx;
   g.kp = premvos::cdiv((int)d.cin_pad, 16) * 16;
   g.bn = wino4_bn(d);
   g.n_tiles = premvos::cdiv(d.cout, g.bn);
@@ -381,9 +387,9 @@ int launch_gemm(const premvos_conv_desc& d, const Geo& g, const float* V, const 
 namespace premvos {
 
 bool conv_wino4_applicable(const premvos_conv_desc& d) {
-  return d.wgt_wino4 != nullptr && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == 1 && d.dw == 1 &&
+  return d.wgt_wino4 != nullptr && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.dh == d.dw && d.dh >= 1 && d.dh <= 64 &&
          d.out_mode == PREMVOS_OUT_NHWC && d.precision == PREMVOS_PREC_F32 && d.cout % 4 == 0 && d.k_pad >= d.cin_pad &&
-         d.ho == d.h + 2 * d.pt - 2 && d.wo == d.w + 2 * d.pl - 2 && d.pt >= 0 && d.pl >= 0;
+         d.ho == d.h + 2 * d.pt - 2 * d.dh && d.wo == d.w + 2 * d.pl - 2 * d.dw && d.pt >= 0 && d.pl >= 0;
 }
 
 long conv_wino4_workspace_bytes(const premvos_conv_desc& d) {

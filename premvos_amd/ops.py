@@ -333,9 +333,9 @@ def _candidates(d: ConvDesc):
         small = d.n * d.h * d.w * d.in_ps < (1 << 30) and 16 * d.cout_pad * _r(d.cin_pad, 16) < (1 << 30)
         if small and os.environ.get("PREMVOS_WINOGRAD_FUSED", "1") != "0":
             out.extend((3, v, -1, 0, 0) for v in (() if d.cout <= 32 else (3, 5) if d.cout <= 64 else (0, 2, 4, 6)))
-    if wino_applicable(d) and bool(d.wgt_wino4) and os.environ.get("PREMVOS_WINOGRAD4", "1") != "0":
+    if (wino_applicable(d) or wino_atrous_applicable(d)) and bool(d.wgt_wino4) and os.environ.get("PREMVOS_WINOGRAD4", "1") != "0":
         # tile_hint 4 = Winograd F(4x4,3x3) (csrc/conv_wino4_f32.hip): 4x fewer multiplies, 2.25x the input + output through slabs
-        mt4 = d.n * -(-d.ho // 4) * -(-d.wo // 4)
+        mt4 = d.n * d.dh * d.dw * -(-(-(-d.ho // d.dh)) // 4) * -(-(-(-d.wo // d.dw)) // 4)      # (atrous: per sub-lattice)
         if 36 * mt4 * (_r(d.cin_pad, 16) + _r(d.cout, 128)) * 4 <= WINO4_MAX_WS:
             out.extend((4, v, -1, 0, 0) for v in (0, 64, 16, 80))     # GEMM block: 128 / 64 tile rows x 32- / 16-deep stages
     if stream_applicable(d):
@@ -795,7 +795,7 @@ def wino4_slab_plan(layers):
         return None
     ends = {off + d.cin for d, off in layers}
     tiles = {d.n * ((d.ho + 3) // 4) * ((d.wo + 3) // 4) for d, _ in layers}
-    if len(ends) != 1 or len(tiles) != 1 or any(off % 16 or d.tile_hint != 4 for d, off in layers):
+    if len(ends) != 1 or len(tiles) != 1 or any(off % 16 or d.tile_hint != 4 or (d.dh, d.dw) != (1, 1) for d, off in layers):
         return None
     kp = lambda d: _r(d.cin_pad, 16)
     pitch = max(off + kp(d) for d, off in layers)

@@ -75,7 +75,7 @@ def test_kept_winograd_slab_plan_of_a_densenet_level():
 
     def desc(off, hint=4, end=597, n=16, h=64, w=112):
         d = ConvDesc()
-        d.n, d.h, d.w, d.ho, d.wo, d.cin, d.tile_hint = n, h, w, h, w, end - off, hint
+        d.n, d.h, d.w, d.ho, d.wo, d.cin, d.tile_hint, d.dh, d.dw = n, h, w, h, w, end - off, hint, 1, 1
         d.cin_pad = (d.cin + 3) // 4 * 4
         return d, off
 

@@ -212,3 +212,30 @@ def test_kept_winograd_slab_of_a_densenet_block_is_bit_identical():
         ops.run_wino4_slab(d1, slab, 16, 0, 16)
     # a block whose windows do not start at multiples of 16 gets no plan (the layers then run self-contained)
     assert ops.wino4_slab_plan([(db[0][0], 321), (db[1][0], 192)]) is None
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,dil", [(2, 128, 128, 32, 40, 2), (1, 128, 96, 37, 29, 4), (1, 128, 128, 40, 56, 8), (1, 160, 64, 33, 50, 16)])
+def test_winograd_4x4_on_atrous_layers_matches_torch(n, cin, cout, h, w, dil):
+    """PWC-Net's context network (PWCNet.py:266-267: 3x3, dilation 2 / 4 / 8 / 16, pad = dilation) on F(4x4,3x3): the d x d
+    interleaved sub-lattices are independent dense problems -- tiles per phase, inputs d pixels apart; maps that are no multiple of
+    4 d, every GEMM block, output into a channel window with a residual."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(cin + dil)
+    x = torch.randn((n, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    r = torch.randn((n, cout, h, w), generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), b.double(), padding=dil, dilation=dil) + r.double(), 0.1)
+    pk = ops.pack_conv(wt, b)
+    xin, rin = _nhwc(x, ops, ps=cin + 4, coff=4), _nhwc(r, ops)
+    d = ops.conv_desc(xin, pk, ops.NHWC.alloc(n, h, w, cout), pad=(dil, dil), dilation=(dil, dil))
+    assert any(c[0] == 4 for c in ops._candidates(d))
+    scale = max(1.0, ref.abs().max().item())
+    for stage_k in (0, 16, 64, 80):
+        out = ops.NHWC.alloc(n, h, w, cout + 8)
+        out.buf.fill_(3.0)
+        ops.conv2d(xin, pk, out.slice(4, cout), pad=(dil, dil), dilation=(dil, dil), act=ops.ACT_LEAKY, res=rin, tile_hint=4, stage_k=stage_k)
+        torch.cuda.synchronize()
+        assert torch.all(out.buf[..., :4] == 3.0) and torch.all(out.buf[..., 4 + cout:] == 3.0)
+        got = out.slice(4, cout).torch().cpu().double()
+        assert (got - ref).abs().max().item() < 2e-4 * scale, (stage_k, dil)
