@@ -38,6 +38,12 @@ for l, st, name, ms, tf, mult in rows:
     agg[key][0] += l; agg[key][1] += ms * mult
 for k, (l, t) in sorted(agg.items(), key=lambda x: -x[1][0])[:30]:
     print(f"  lost {l:7.2f} ms  time {t:7.2f} ms  {k}")
+if os.environ.get("LT_STAGE"):          # every conv of one stage, by time (LT_STAGE=flow|prop_g|prop_s|refine)
+    print(f"all conv layers of stage {os.environ['LT_STAGE']}, by time:")
+    sel = [r for r in rows if r[1] == os.environ["LT_STAGE"]]
+    print(f"  {sum(r[3] * r[5] for r in sel):.2f} ms/step in {len(sel)} layers")
+    for l, st, name, ms, tf, mult in sorted(sel, key=lambda r: -r[3] * r[5]):
+        print(f"  {ms*1e3:8.1f} us x{mult}  {tf:6.1f} TF/s  lost {l:5.2f} ms  {name}")
 print("3x3 stride-1 layers (Winograd candidates):")
 for l, st, name, ms, tf, mult in rows:
     if "winograd" in name:
