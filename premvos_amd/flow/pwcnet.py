@@ -236,7 +236,9 @@ class PWCDCNet:
             else:
                 # F(4x4,3x3) from 64 input channels here (the other nets: 128): conv2_0 757 -> 600 us, dc_conv6 407 -> 335, conv3aa / conv3b
                 # 167 -> 139 (tools/dev/cands_3x3.py); its ~1e-5 rounding is two orders below the flow's 1e-3 px bar
-                packed[key] = ops.pack_conv(w, bia, self.device, precision=self.precision, wino4_min_c=FLOW_WINO4_MIN_C)
+                # (the stride-2 pyramid layers conv*a cannot run it: they keep the default, and with it their table signatures)
+                strided = key in {PYR[lvl][0] for lvl in PYR}
+                packed[key] = ops.pack_conv(w, bia, self.device, precision=self.precision, wino4_min_c=None if strided else FLOW_WINO4_MIN_C)
         if strict:
             need = set()
             for lv in PYR.values():
