@@ -30,6 +30,28 @@ long conv2d_bf16_workspace_bytes(const premvos_conv_desc& d);
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+#ifdef PV_DBG_TIMELINE          // developer build (tools/dev/ab_build.sh tl -DPV_DBG_TIMELINE): per-workgroup phase stamps
+__device__ unsigned long long g_tl[1 << 20];
+#define PV_TL(slot)                                                                                         \
+  do {                                                                                                      \
+    if (threadIdx.x == 0) {                                                                                 \
+      const unsigned wgl = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                  \
+      if (wgl < (1u << 17)) g_tl[wgl * 8 + (slot)] = __builtin_readcyclecounter();                         \
+      if ((slot) == 0 && wgl < (1u << 17)) {                                                                \
+        g_tl[wgl * 8 + 4] = wall_clock64();                                                                 \
+        g_tl[wgl * 8 + 5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));                                      \
+        g_tl[wgl * 8 + 6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));                                     \
+      }                                                                                                     \
+      if ((slot) == 3 && wgl < (1u << 17)) g_tl[wgl * 8 + 7] = wall_clock64();                              \
+    }                                                                                                       \
+  } while (0)
+extern "C" int premvos_dbg_timeline(void* dst, long bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tl), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define PV_TL(slot) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BK = 16;           // k granularity of the packed weights (k_pad % 16 == 0)
@@ -45,8 +67,13 @@ constexpr int BK = 16;           // k granularity of the packed weights (k_pad %
 #ifndef PV_OCC128
 #define PV_OCC128 3      // workgroups per CU the 128x128 tile is compiled for (developer builds: -DPV_OCC128=4)
 #endif
+// workgroups per CU a tile is compiled for: the 64 x 128 / 128 x 64 wave tiles (128 accumulator registers) run two 4-wave
+// workgroups per CU inside 256 registers
+constexpr int occ_of(int bm, int bn, int wm, int wn, bool pixshuf) {
+  return (bm == 128 && bn == 128 && !pixshuf) ? PV_OCC128 : (bm * bn == 128 * 256 && wm * wn == 4 && !pixshuf) ? 2 : 1;
+}
 template <int BM, int BN, int WM, int WN, bool PIXSHUF, bool SPLITK, int KB = 16, bool PW = false>
-__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) ? PV_OCC128 : 1) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
+__global__ __launch_bounds__(64 * WM * WN, occ_of(BM, BN, WM, WN, PIXSHUF)) void conv_igemm_f32_kernel(const premvos_conv_desc p, const int kt_per, const int mt0) {
   constexpr int NT = 64 * WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NTL = WTN / 32;
@@ -60,6 +87,10 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   float(*lds)[BUF] = reinterpret_cast<float(*)[BUF]>(lds_dyn);
 
+  PV_TL(0);
+#ifdef PV_EDGE_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
@@ -189,6 +220,10 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
   gload(kt_begin);
   lstore(0);
   __syncthreads();
+  PV_TL(1);
+#ifdef PV_EDGE_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 
   // Padding that is never multiplied (round 3).  (1) Columns: a wave whose 32-column blocks lie (partly) beyond cout -- the last
   // column tile of the 728-wide Xception layers holds 88 real columns of 128 -- skips the MFMAs and B-fragment reads of its
@@ -290,6 +325,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
       for (int mi = mi0; mi < mi1; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NV; ++ni) {
+#ifdef PV_ASM_CHAIN
+          // developer variant (round 5): the four dependent MFMAs of one accumulator as ONE opaque statement -- the scheduler cannot
+          // put a request / fragment read / address instruction between two of them (a break in a dependent chain costs the pipe
+          // ~43 cycles, MI355X_MICROARCH.md), only between chains
+          asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\tv_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+                       "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\tv_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+                       : "+v"(acc[mi][ni])
+                       : "v"(af[set][mi].x), "v"(af[set][mi].y), "v"(af[set][mi].z), "v"(af[set][mi].w), "v"(bf[set][ni].x),
+                         "v"(bf[set][ni].y), "v"(bf[set][ni].z), "v"(bf[set][ni].w));
+          continue;
+#endif
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].x, bf[set][ni].x, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].y, bf[set][ni].y, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][mi].z, bf[set][ni].z, acc[mi][ni], 0, 0, 0);
@@ -297,6 +343,41 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
         }
     };
     static_assert(H % 2 == 0, "the two fragment sets alternate per 8-deep group");
+#ifdef PV_EARLY_STORE
+    // Developer variant (round 5): the staging registers are stored at the START of a stage (their requests went out a whole stage
+    // earlier) and refilled at once with the stage after the next -- the ds_write traffic and its lgkmcnt wait move away from
+    // the barrier, and a request has a full stage to come back.
+    ldfrag(0, 0, 0);
+    if (KT > 1) gload(kt_begin + 1);
+    auto stage = [&](const int kt, auto mode_tag) {       // 0: nothing left to request, 1: predicated request, 2: plain
+      constexpr int MODE = decltype(mode_tag)::value;
+      const int buf = kt & 1;
+      lstore(buf ^ 1);
+      if constexpr (MODE == 2) {
+        gload_plain(kt_begin + kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (MODE == 1) gload(kt_begin + kt + 2);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int h = 0; h + 1 < H; ++h) {
+        ldfrag((h + 1) & 1, buf, h + 1);
+        mfma_rows(h & 1, 0, MT);
+      }
+      mfma_rows((H - 1) & 1, 0, MT - 1);
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();
+      ldfrag(0, buf ^ 1, 0);
+      mfma_rows((H - 1) & 1, MT - 1, MT);
+    };
+    int kt = 0;
+    if constexpr (PW && A_UNITS % NT == 0 && B_UNITS % NT == 0) {
+      const bool interior = m0 + BM <= M && n0 + BN <= p.cout_pad && (KT_all - 1) * KB <= p.cin_pad;
+      if (interior)
+        for (; kt_begin + kt + 2 < KT_all - 1 && kt + 2 < KT; ++kt) stage(kt, std::integral_constant<int, 2>{});
+    }
+    for (; kt + 2 < KT; ++kt) stage(kt, std::integral_constant<int, 1>{});
+    for (; kt + 1 < KT; ++kt) stage(kt, std::integral_constant<int, 0>{});
+#else
     ldfrag(0, 0, 0);
     auto stage = [&](const int kt, auto plain_tag) {
       const int buf = kt & 1;
@@ -338,6 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
     }
 #endif
     for (; kt + 1 < KT; ++kt) stage(kt, std::false_type{});
+#endif
     const int buf = (KT - 1) & 1;
     const int hcnt = ends_matrix ? h_last : H;
 #pragma unroll
@@ -393,9 +475,14 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
   }
   if (done) {
   } else if (nvalid == NTL) k_loop(std::integral_constant<int, NTL>{});
+  else if (NTL > 3 && nvalid == 3) k_loop(std::integral_constant<int, (NTL > 3 ? 3 : 0)>{});
   else if (NTL > 2 && nvalid == 2) k_loop(std::integral_constant<int, (NTL > 2 ? 2 : 0)>{});
   else if (NTL > 1 && nvalid == 1) k_loop(std::integral_constant<int, (NTL > 1 ? 1 : 0)>{});
   else k_loop(std::integral_constant<int, 0>{});
+  PV_TL(2);
+#ifdef PV_EDGE_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
 
   if constexpr (SPLITK) {   // raw partial slab, ncols = gridDim.y * BN (padded: no column predicate needed)
     const int ncols = gridDim.y * BN;
@@ -423,7 +510,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
                       (p.res == nullptr || ((p.res_ps & 3) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15u) == 0)) &&
                       (p.bias == nullptr || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0);
     constexpr int EP = BN + 4;                                   // row pitch of the staged block (floats)
-    static_assert(WTM * EP <= 2 * BUF, "the staged wave row must fit the operand buffers");
+    // (tiles whose staged wave row outgrows the operand buffers get the difference as extra dynamic LDS: lds_floats())
 #ifdef PV_DBG_NOEPI             // developer phase ablation (tools/dev/ab_build.sh): no epilogue at all; the accumulators stay live
     if (wide) {
       float sacc = 0.f;
@@ -491,6 +578,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
           }
           __builtin_amdgcn_wave_barrier();
         }
+        PV_TL(3);
         return;
       }
     }
@@ -596,6 +684,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && !PIXSHUF) 
         }
         if (wr + 1 < WM) __syncthreads();
       }
+      PV_TL(3);
       return;
     }
   }
@@ -744,7 +833,8 @@ int launch_cfg(const premvos_conv_desc& d, hipStream_t s) {
 #ifndef PV_DBG_LDS_PAD
 #define PV_DBG_LDS_PAD 0          // developer builds: extra dynamic LDS per workgroup = fewer workgroups per CU (occupancy experiments)
 #endif
-  constexpr int LDS_BYTES = 2 * (BM + BN) * (KB + 4) * (int)sizeof(float) + PV_DBG_LDS_PAD;
+  constexpr int OPER = 2 * (BM + BN) * (KB + 4), STAGED = (BM / WM) * (BN + 4);     // floats: operand buffers | one staged wave row
+  constexpr int LDS_BYTES = (OPER > STAGED ? OPER : STAGED) * (int)sizeof(float) + PV_DBG_LDS_PAD;
   static const bool attr_done = [] {            // once per instantiation, thread-safe (the file drivers launch from several threads)
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, false, true, KB>, LDS_BYTES);
     allow_lds(conv_igemm_f32_kernel<BM, BN, WM, WN, true, false, KB>, LDS_BYTES);
@@ -918,6 +1008,9 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   switch ((bm << 16) | bn) {
     case (256 << 16) | 128: return launch_cfg<256, 128, 4, 2>(d, s);      // 8 waves of 64x64: half the B staging per MFMA
     case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2>(d, s);
+    case (128 << 16) | 256: return launch_cfg<128, 256, 2, 2>(d, s);      // 4 waves of 64x128
+    case (256 << 16) | 129: return launch_cfg<256, 128, 2, 2>(d, s);      // 4 waves of 128x64 (hint 256x129)
+    case (256 << 16) | 256: return launch_cfg<256, 256, 4, 2>(d, s);      // 8 waves of 64x128
     case (128 << 16) | 96: return launch_cfg<128, 96, 4, 1>(d, s);
     case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2>(d, s);
     case (128 << 16) | 32: return launch_cfg<128, 32, 4, 1>(d, s);
@@ -941,6 +1034,9 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   switch ((bm << 16) | bn) {
     case (256 << 16) | 128: return ws_cfg<256, 128, 4, 2>(*dp);
     case (128 << 16) | 128: return ws_cfg<128, 128, 2, 2>(*dp);
+    case (128 << 16) | 256: return ws_cfg<128, 256, 2, 2>(*dp);
+    case (256 << 16) | 129: return ws_cfg<256, 128, 2, 2>(*dp);
+    case (256 << 16) | 256: return ws_cfg<256, 256, 4, 2>(*dp);
     case (128 << 16) | 96: return ws_cfg<128, 96, 4, 1>(*dp);
     case (128 << 16) | 64: return ws_cfg<128, 64, 2, 2>(*dp);
     case (128 << 16) | 32: return ws_cfg<128, 32, 4, 1>(*dp);

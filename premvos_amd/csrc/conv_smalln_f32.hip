@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv_smalln_tile_kernel(const premvos_
       for (int b = 0; b < TX; ++b)
 #pragma unroll
         for (int co = 0; co < NOUT; ++co) acc[a][b][co] = 0.f;
-    // patch rows / columns outside the map: clamped addresses (always readable), the loaded value multiplied by zero
+    // patch rows / columns outside the map: clamped addresses (always readable), the loaded value replaced by zero
     int xoff[TX + 2];
-    float mx[TX + 2], my[TY + 2];                          // 1 inside the map, 0 outside (the activations are finite: 0 * v = 0)
+    float mx[TX + 2], my[TY + 2];                          // 1 inside the map, 0 outside (selects the loaded value or 0)
 #pragma unroll
     for (int q = 0; q < TX + 2; ++q) {
       const int ix = ox0 - 1 + q;
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void conv_smalln_tile_kernel(const premvos_
         for (int q = 0; q < TX + 2; ++q) {
           float m = mx[q];
           asm volatile("" : "+v"(m));
-          m *= my[r];
-          v[q] = make_float4(v[q].x * m, v[q].y * m, v[q].z * m, v[q].w * m);
+          const bool in = m * my[r] != 0.f;                  // selected, not multiplied: 0 * Inf / NaN of a clamped border pixel
+          v[q] = in ? v[q] : make_float4(0.f, 0.f, 0.f, 0.f);  // must not reach a sum that true zero padding leaves finite
         }
 #pragma unroll
         for (int a = 0; a < TY; ++a) {

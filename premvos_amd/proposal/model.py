@@ -280,7 +280,8 @@ class ProposalNet:
         w = weights
         # bf16x3 (split-fp32) mode, round 4: from group ``s8_from`` on (PREMVOS_BF16X3_S8_FROM, default 1: group0's K = 64 layers are
         # HBM-bound on any pipe) every conv of the bottleneck chains, the RPN 3x3 and conv5 runs on csrc/conv_bf16x3_s8.hip with its
-        # input resident in the split layout S8; the rest (conv0, group0, the 75- / 87-channel heads) on the on-the-fly bf16x3 kernel
+        # input resident in the split layout S8; conv0 and group0 stay on the fp32 kernels the shipped table tunes (packed with
+        # precision="fp32" below), the 75- / 87-channel heads run on the on-the-fly bf16x3 kernel
         import os
         self.s8 = prec == "bf16x3" and os.environ.get("PREMVOS_BF16X3_SPLIT", "1") != "0"
         self.s8_from = int(os.environ.get("PREMVOS_BF16X3_S8_FROM", "1"))

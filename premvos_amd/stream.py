@@ -210,6 +210,10 @@ class StreamPipeline:
                 """ONE thread issues the collectives, in chunk order: round k = this rank's k-th chunk (a filler when it has none);
                 the gather of round k is in flight while round k + 1 is computed / packed; the merge rank decodes round k - 1."""
                 try:
+                    # the current device is per host thread and a new thread starts on device 0: select this rank's GPU before
+                    # anything allocates, launches or synchronises here (ranks with LOCAL_RANK > 0 would otherwise pack on GPU 0)
+                    if gather.device.type == "cuda":
+                        torch.cuda.set_device(gather.device)
                     x, pending, held = gather.x, {}, None
                     filler = gather.staging()
                     prev = None                        # (round, slot) whose gather was issued last
@@ -227,7 +231,8 @@ class StreamPipeline:
                         if cur is not filler:          # (packed: the staging block can take the next chunk)
                             for key in ("flow", "masks"):
                                 cur[key].zero_()
-                            torch.cuda.current_stream().synchronize()      # packed and cleared before a stage stream writes it again
+                            if gather.device.type == "cuda":                 # packed and cleared before a stage stream writes it again
+                                torch.cuda.current_stream(gather.device).synchronize()
                             free_stg.put(cur)
                         if prev is not None:
                             self._decode_round(gather, prev, writer)
@@ -236,6 +241,8 @@ class StreamPipeline:
                         self._decode_round(gather, prev, writer)
                 except BaseException as e:             # noqa: BLE001
                     errors.append(e)
+                    xdead.set()                        # the producer polls this: nobody returns staging blocks any more
+            xdead = threading.Event()
             xthread = threading.Thread(target=exchange_loop, name="premvos-exchange", daemon=True)
             xthread.start()
         q_flow, q_g, q_s, q_rg, q_rs = (queue.Queue(maxsize=3) for _ in range(5))
@@ -287,7 +294,18 @@ class StreamPipeline:
                         break
                     stg = None
                     if gather is not None:
-                        stg = free_stg.get()
+                        if n_chunks >= len(gather.chunks[gather.rank]):
+                            raise RuntimeError(f"--gather: {seq} yields more chunks than the shard plan lists for rank {gather.rank} "
+                                               f"({len(gather.chunks[gather.rank])}): every frame of a video must have one size")
+                        if tuple(frames[0].shape[:2]) != tuple(gather.chunks[gather.rank][n_chunks][3]):
+                            raise RuntimeError(f"--gather: {seq}/{names[0]} is {tuple(frames[0].shape[:2])}, the video's first frame is "
+                                               f"{tuple(gather.chunks[gather.rank][n_chunks][3])}: one size per video required")
+                        while stg is None:             # only the exchange thread returns blocks: do not outwait its death
+                            try:
+                                stg = free_stg.get(timeout=0.5)
+                            except queue.Empty:
+                                if errors or xdead.is_set() or not xthread.is_alive():
+                                    raise RuntimeError("the exchange thread stopped before this chunk got a staging block")
                         left, lock, idx = {"flow", "general", "specific", "refine"}, threading.Lock(), n_chunks
 
                         def done(part, stg=stg, left=left, lock=lock, idx=idx):
@@ -458,9 +476,11 @@ class DeviceGather:
         n = len(names)
         u = self.x.unpack(buf)
         files = 0
+        # (copies: on the host-staged path .cpu().numpy() is a VIEW of the gather slot, which the gather two rounds on overwrites
+        #  while the asynchronous writer may still hold these arrays)
         flow = u["flow"][:n, :h, :w].cpu().numpy()
         for i in range(n - (0 if has_next else 1)):
-            writer.submit(_write_flo, os.path.join(out, "flow", seq, names[i] + ".flo"), np.ascontiguousarray(flow[i]))
+            writer.submit(_write_flo, os.path.join(out, "flow", seq, names[i] + ".flo"), np.array(flow[i], copy=True, order="C"))
             files += 1
         nh, nw = custom_resize_shape(h, w)
         scale = (nh * 1.0 / h + nw * 1.0 / w) / 2
@@ -471,7 +491,7 @@ class DeviceGather:
             for i in range(n):
                 writer.submit(_dump_json, os.path.join(out, which + "_proposals", seq, names[i] + ".json"), lists[which][i])
                 files += 1
-        conf = u["conf"][:n].cpu().numpy()
+        conf = u["conf"][:n].cpu().numpy().copy()
         masks = u["masks"]
         if not masks.is_cuda:
             masks = masks.to("cuda")
