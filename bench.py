@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=int(os.environ.get("PREMVOS_BENCH_FRAMES", "0")),
                     help="strong scaling: frame pairs of the video (default 8 chunks = 8 x --batch: one chunk per GPU of an 8-GPU node per pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--supplementary", default=os.environ.get("PREMVOS_BENCH_SUPPLEMENTARY", "mixed-bf16x3,1080p"),
+                    help="after the fp32 line's timed region (N = 1, 480p, fp32 only): short passes of these further modes, measured by "
+                         "this same run into the `supplementary` object -- comma-separated from {mixed-bf16x3, 1080p}; 'none' skips")
     ap.add_argument("--cpu-baseline-worker", default=None, metavar="K:CORES", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--file-to-file", type=int, default=int(os.environ.get("PREMVOS_BENCH_F2F_FRAMES", "128")), metavar="FRAMES",
@@ -223,7 +226,93 @@ def file_to_file(n_frames: int, chunk: int):
 PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
-def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32"):
+class BoxSampler:
+    """Shader clock / socket power / temperatures of THIS rank's GPU, sampled by a host thread (amdsmi, ~20 Hz) while the timed
+    region runs: the line then says under which clock and power the number was measured (the fp32 MFMA kernels run the socket
+    at its 1.4 kW cap and the clock gives way by 3 ... 5 %: profiles/r05_igemm_investigation.md).  A box that does not expose
+    amdsmi yields {"error": ...}; nothing else depends on it."""
+
+    def __init__(self, index: int, period_s: float = 0.05):
+        import threading
+        self.samples, self.err, self._stop, self.period = [], None, threading.Event(), period_s
+        try:
+            import amdsmi
+            self.smi = amdsmi
+            try:
+                amdsmi.amdsmi_init()
+            except Exception:                  # noqa: BLE001 -- (already initialised by another object of this process)
+                pass
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self.h = hs[index % len(hs)]
+            self._read()                       # fail here, not in the thread
+        except Exception as e:                 # noqa: BLE001
+            self.err = f"{type(e).__name__}: {e}"[:200]
+        self.th = threading.Thread(target=self._loop, daemon=True)
+
+    def _read(self):
+        m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+        clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+        num = lambda v: float(v) if isinstance(v, (int, float)) else None       # noqa: E731
+        return (sum(clk) / len(clk) if clk else num(m.get("current_gfxclk")), min(clk) if clk else None,
+                num(m.get("current_socket_power")), num(m.get("temperature_hotspot")), num(m.get("temperature_mem")),
+                num(m.get("current_uclk")), num(m.get("ppt_residency_acc")), num(m.get("accumulation_counter")))
+
+    def _loop(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(self._read())
+            except Exception as e:             # noqa: BLE001
+                self.err = f"{type(e).__name__}: {e}"[:200]
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.err is None:
+            self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.th.is_alive():
+            self.th.join()
+
+    def summary(self) -> dict:
+        if self.err is not None and not self.samples:
+            return {"error": self.err}
+        col = lambda i: [s[i] for s in self.samples if s[i] is not None]        # noqa: E731
+        stat = lambda v, nd=0: {"min": round(min(v), nd), "mean": round(sum(v) / len(v), nd), "max": round(max(v), nd)} if v else None   # noqa: E731
+        ppt, acc = col(6), col(7)
+        return {"samples": len(self.samples), "period_s": self.period,
+                "sclk_mhz_mean_of_xcds": stat(col(0)), "sclk_mhz_slowest_xcd": stat(col(1)), "socket_power_w": stat(col(2)),
+                "temperature_hotspot_c": stat(col(3)), "temperature_mem_c": stat(col(4)), "uclk_mhz": stat(col(5)),
+                # share of the region the firmware reports as power-limited (PPT residency counter / accumulation counter)
+                "power_limited_share": round((ppt[-1] - ppt[0]) / (acc[-1] - acc[0]), 3) if len(ppt) > 1 and len(acc) > 1 and acc[-1] > acc[0] else None,
+                "source": "amdsmi_get_gpu_metrics_info on a host thread during the timed region (nominal sclk 2400 MHz, socket cap 1400 W)"}
+
+
+def hbm_ceiling():
+    """What a float4 copy sustains on THIS GPU (read + write bytes / time; 1 GiB -> 1 GiB, far beyond the 256 MB Infinity Cache)."""
+    from premvos_amd import _lib
+    lib = _lib.load()
+    n = 1 << 28                                      # floats per buffer
+    src = torch.full((n,), 1.0, dtype=torch.float32, device="cuda")
+    dst = torch.empty_like(src)
+    st = _lib.current_stream()
+    for _ in range(2):
+        _lib.check(lib.premvos_hbm_copy_calibrate(src.data_ptr(), dst.data_ptr(), n // 4, st), "hbm_copy_calibrate")
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.check(lib.premvos_hbm_copy_calibrate(src.data_ptr(), dst.data_ptr(), n // 4, st), "hbm_copy_calibrate")
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    del src, dst
+    return round(2.0 * 4 * n / (sorted(ts)[len(ts) // 2] * 1e-3) / 1e9, 1)
+
+
+def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32", calibrate=True):
     """Dominant kernel = conv_igemm_f32_kernel (every dense conv of the three nets).  HIP events around every one
     of its launches of one step, on the stream they are launched on; achieved = algorithmic FLOPs / time."""
     reps = 5
@@ -265,15 +354,18 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32"):
     alg_bytes = sum(it[4] for it in items)
     # what the fp32 MFMA pipe sustains on THIS GPU with nothing else going on (pure v_mfma_f32_32x32x2_f32 loop)
     from premvos_amd import _lib
-    sink = torch.zeros(4, device="cuda")
-    lib, blocks, iters = _lib.load(), 1024, 20000
-    lib.premvos_mfma_f32_calibrate(1000, blocks, sink.data_ptr(), _lib.current_stream())
-    ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ca.record()
-    lib.premvos_mfma_f32_calibrate(iters, blocks, sink.data_ptr(), _lib.current_stream())
-    cb.record()
-    cb.synchronize()
-    ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
+    ceiling = hbm_gbs = float("nan")
+    if calibrate:
+        sink = torch.zeros(4, device="cuda")
+        lib, blocks, iters = _lib.load(), 1024, 20000
+        lib.premvos_mfma_f32_calibrate(1000, blocks, sink.data_ptr(), _lib.current_stream())
+        ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ca.record()
+        lib.premvos_mfma_f32_calibrate(iters, blocks, sink.data_ptr(), _lib.current_stream())
+        cb.record()
+        cb.synchronize()
+        ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
+        hbm_gbs = hbm_ceiling()
     if net_prec != "fp32":
         # the optional bf16-MFMA modes (never the headline): priced against the dense bf16 peak.  bf16x3 issues three MFMAs per
         # product (hi.hi + hi.lo + lo.hi), so its issue fraction is 3x its algorithmic fraction.
@@ -312,6 +404,9 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32"):
                        "igemm_family_frac, winograd_issued_frac and mfma_issue_frac for that",
             "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": round(alg_bytes / nl), "mfma_ceiling_measured": round(ceiling, 1),
+            # the box factor of the memory system (GB/s of a float4 copy, read + write) and ONE canonical layer of the pipeline --
+            # Xception middle flow 728 -> 728 pointwise + residual at M = 100 000 pixels (xception.py:508-550), as this run timed it
+            "hbm_ceiling_measured": hbm_gbs, **_canonical_layer(items, tot),
             # the split of `frac`: a Winograd layer issues 16/36 or 36/144 of its algorithmic FLOPs, so the
             # headline fraction is not pipe utilisation.  `igemm_family_frac`: the layers that multiply every algorithmic FLOP
             # (implicit GEMM incl. k-slab / tail-split launches, the streaming pointwise kernel, the 1-2 channel direct heads) --
@@ -321,6 +416,15 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32"):
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),
             "conv_ms_per_step": round(ms, 3), "conv_ms_each_layer_once": round(sum(tot), 3),
             "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
+
+
+def _canonical_layer(items, tot):
+    name = "conv:middle_flow/block1/unit_8/xception_module/separable_conv3_pointwise"
+    for (st, n, _, f, _, d), t in zip(items, tot):
+        if st == "refine" and n == name:
+            return {"canonical_layer": {"what": f"{n[5:]}: {d.cin} -> {d.cout} 1x1 + residual, M = {d.n * d.ho * d.wo} pixels, one launch",
+                                        "us": round(1e3 * t, 1), "tflops": round(2.0 * d.n * d.ho * d.wo * d.cin * d.cout / (t * 1e-3) / 1e12, 1)}}
+    return {"canonical_layer": None}
 
 
 RIDGE_F32 = PEAK_F32_TFLOPS * 1e12 / 6.29e12      # FLOP per HBM byte above which an fp32 conv is MFMA-bound (6.29 TB/s achievable)
@@ -362,6 +466,51 @@ def _family_split(items, tot, mult):
                                        "tflops": tf(fl_h, t_h), "share_of_conv_time": round(t_h / (t_i + t_w), 4) if t_i + t_w else None},
             "winograd_algorithmic_tflops": tf(fl_w, t_w),
             "winograd_issued_frac": round(is_w / (t_w * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4) if t_w else None}
+
+
+def supplementary_pass(mode: str, B: int, dev, passes: int = 3) -> dict:
+    """One supplementary mode under this run's clock: its own pipeline object, one warm-up pass and
+    ``passes`` timed passes over a synthetic video of 8 chunks (two distinct chunks of frames in HBM, walked four times), and the
+    dense-conv roofline leg of that object.  ``mixed-bf16x3``: configs[2]'s arithmetic as this build reads it (PWC-Net fp32,
+    proposal + refinement split-fp32 on the bf16 MFMA pipe, fp32 accumulate: plain bf16 misses north_star's 1e-3 / bit-exact-index
+    bars, tests/test_gpu_error_budget.py); ``1080p``: configs[4]'s frame shape in fp32.  Never the metric's line."""
+    from premvos_amd import synth
+    from premvos_amd.pipeline import FramePipeline
+    h, w = (1080, 1920) if mode == "1080p" else (480, 854)
+    net_prec, flow_prec = ("bf16x3", "fp32") if mode == "mixed-bf16x3" else ("fp32", "fp32")
+    t_build = time.perf_counter()
+    pipe = FramePipeline(synth.pwc_state_dict(0), synth.proposal_weights(0), synth.proposal_weights(1), synth.refinement_weights(0),
+                         batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec, flow_precision=flow_prec)
+    clip = synth.clip_frames(0, 2 * B + 1, h, w).to(dev)
+    bx = synth.clip_boxes(0, 2 * B, P_BOXES, h, w).to(dev)
+    chunks = [(clip[c:c + B].contiguous(), clip[c + 1:c + B + 1].contiguous(), bx[c:c + B].contiguous()) for c in (0, B)]
+    n_launch = 8
+
+    def one_pass():
+        for k in range(n_launch):
+            pipe.step(*chunks[k % 2])
+    one_pass()
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    with BoxSampler(dev.index or 0) as smi:
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            one_pass()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    rf = roofline(pipe, B, net_prec, flow_prec, calibrate=False)
+    keep = ("kernel", "achieved", "peak", "unit", "frac", "mfma_issue_frac", "igemm_family_frac", "winograd_issued_frac",
+            "per_stage_tflops", "conv_ms_per_step", "launches_per_step", "note")
+    box = smi.summary()
+    out = {"value": round(passes * n_launch * B / dt, 2), "unit": "frames/s", "frame": f"{h}x{w}",
+           "dtype": "flow f32; proposal+refinement bf16x3 (split-fp32 on the bf16 MFMA pipe, f32 accumulate)" if mode == "mixed-bf16x3" else "f32",
+           "ms_per_launch": round(1e3 * dt / (passes * n_launch), 2), "frames_per_launch": B, "launches_timed": passes * n_launch,
+           "build_and_first_pass_s": round(t_build, 1), "measured_by_this_run": True,
+           "roofline": {k: rf[k] for k in keep if k in rf},
+           "box": {k: box.get(k) for k in ("sclk_mhz_mean_of_xcds", "socket_power_w", "power_limited_share", "error") if box.get(k) is not None}}
+    del pipe, chunks, clip, bx
+    torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(a) -> int:
@@ -441,6 +590,7 @@ def main():
     from premvos_amd.parallel import ResultExchange
     from premvos_amd.pipeline import FramePipeline
 
+    t_proc = time.perf_counter()                    # cold start of this rank: from here to the end of its first step
     B = a.batch
     prec = a.precision
     flow_prec = "fp32" if prec.startswith("mixed") else prec
@@ -450,7 +600,9 @@ def main():
                          synth.refinement_weights(0), batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec,
                          flow_precision=flow_prec)
     strong = a.scaling == "strong"
-    T = (a.frames if a.frames > 0 else 8 * B) if strong else B * world
+    # strong scaling: the documented default video is 16 chunks (256 frame pairs at --batch 16): TWO launches per rank and pass at
+    # N = 8, so that one slow launch is not the whole step; --frames overrides
+    T = (a.frames if a.frames > 0 else 16 * B) if strong else B * world
     xchg = ResultExchange(B, H, W, P_BOXES, dev) if use_dist else None
     if strong:
         # the product's own sharding of ONE video (premvos_amd.stream.run): chunk-aligned frame ranges; frame pair t = (t, t+1)
@@ -497,32 +649,62 @@ def main():
                 xchg.exchange_async(r)
             return r
 
+    t_first = None
     if world > 1 and rank == 0:
         pipe.step(fa, fb, boxes)          # builds + tunes every plan (no collective: the other ranks wait in publish())
         torch.cuda.synchronize()
+        t_first = time.perf_counter()
+    t_w = time.perf_counter()
     publish()
-    if strong and not chunks:
-        last["r"] = pipe.step(fa, fb, boxes)            # something to pack for the gathers this rank only takes part in
+    waited = time.perf_counter() - t_w if world > 1 and rank != 0 else 0.0      # (for rank 0's tuning: not this rank's cold start)
+    if t_first is None:
+        r0 = pipe.step(fa, fb, boxes)     # first launch of this rank: plans, graphs (and something to pack for the gathers a
+        if strong:                        # chunk-less rank only takes part in)
+            last["r"] = r0
+        torch.cuda.synchronize()
+        t_first = time.perf_counter()
+    cold_start_s = t_first - t_proc - waited     # process start (after argument parsing / rendezvous) -> end of the first launch
+    smi = BoxSampler(dev.index or 0)
     for _ in range(a.warmup):
         step()
     if use_dist:
         xchg.flush()
         dist.barrier()
+        xchg.wait_s = 0.0
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    if use_dist:
-        xchg.flush()                      # every gather has landed on the merge rank inside the timed region
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with smi:
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        if use_dist:
+            xchg.flush()                      # every gather has landed on the merge rank inside the timed region
+        torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0     # this rank's own work + its exchanges, before it waits for the others
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    per_rank = None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # scaling diagnostics (no curve is claimed from them): what every rank spent on its own, how long it sat in
+        # ResultExchange.wait / flush, how far apart the ranks finished, and its cold start
+        mine = {"rank": rank, "ms_per_step": round(1e3 * dt_own / a.steps, 3), "launches_per_step": len(chunks) if strong else 1,
+                "exchange_wait_ms_per_step": round(1e3 * xchg.wait_s / a.steps, 3), "cold_start_s": round(cold_start_s, 2),
+                "sclk_mhz_mean": ((smi.summary().get("sclk_mhz_mean_of_xcds") or {}).get("mean") if smi.err is None else None)}
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        own = [r["ms_per_step"] for r in rows]
+        per_rank = {"ms_per_step": own, "launches_per_step": [r["launches_per_step"] for r in rows],
+                    "exchange_wait_ms_per_step": [r["exchange_wait_ms_per_step"] for r in rows],
+                    "cold_start_s": [r["cold_start_s"] for r in rows], "sclk_mhz_mean": [r["sclk_mhz_mean"] for r in rows],
+                    "rank_skew_ms_per_step": round(max(own) - min(own), 3),
+                    "slowest_rank": int(max(range(world), key=lambda k: own[k])),
+                    "what": "ms_per_step: a rank's own launches + its gathers (before the closing barrier); exchange_wait: time blocked "
+                            "in ResultExchange.wait / flush (a gather that did not finish under the next chunk's compute); skew = "
+                            "slowest - fastest rank; `ms_per_step` of the line is the max over ranks incl. the barrier"}
 
     frames = a.steps * T
     out = {
@@ -534,6 +716,7 @@ def main():
                   "mixed-bf16x3": "flow f32; proposal+refinement bf16x3 (split-fp32, f32 accumulate)",
                   "mixed-bf16": "flow f32; proposal+refinement bf16 (f32 accumulate)"}[prec],
         "data": "synthetic",
+        "box": smi.summary(),          # clock / power / temperature of rank 0's GPU over the timed region
         "config": {"workload": ("configs[3] on one node: full per-frame pipe on synthetic DAVIS-shape 480x854 uint8 frames in "
                                 "HBM: PWC-Net flow (512x896) + proposal_net x2 weight sets (749x1333, ResNet-101-C4, 100 RoIs) "
                                 if a.frame == "480p" else
@@ -552,6 +735,9 @@ def main():
                                   f"{'RCCL' if backend == 'nccl' else backend} gather per chunk of one packed buffer per rank "
                                   f"({xchg.nbytes if xchg else 0} B: flow f32, masks bit-packed, boxes/scores/conf) to rank 0"},
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
+    out["cold_start_s"] = round(cold_start_s, 2)
     if rank == 0:
         from premvos_amd import ops
         out["conv_configurations"] = ops.tune_info()     # which table / rule froze the kernels (reproducibility)
@@ -564,6 +750,21 @@ def main():
                 out["file_to_file"] = file_to_file(a.file_to_file, int(os.environ.get("PREMVOS_STREAM_BATCH", "8")))
             except Exception as e:           # noqa: BLE001 -- a secondary leg must not take the contract line down
                 out["file_to_file"] = {"error": f"{type(e).__name__}: {e}"[:300], "measured_by_this_run": False}
+        # supplementary modes under the same run's clock (never `value`): the fp32 object is freed first
+        modes = [m for m in a.supplementary.split(",") if m in ("mixed-bf16x3", "1080p")]
+        if world == 1 and a.frame == "480p" and prec == "fp32" and modes:
+            pipe = step = fa = fb = boxes = None
+            if strong:
+                chunks.clear()
+                last["r"] = None
+            torch.cuda.empty_cache()
+            out["supplementary"] = {}
+            for m in modes:
+                try:
+                    out["supplementary"][m] = supplementary_pass(m, B, dev)
+                except Exception as e:       # noqa: BLE001 -- a secondary leg must not take the contract line down
+                    out["supplementary"][m] = {"error": f"{type(e).__name__}: {e}"[:300], "measured_by_this_run": False}
+                    torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

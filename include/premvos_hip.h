@@ -319,6 +319,11 @@ int premvos_refine_output_f32(const float* logits, int32_t logits_ps, int32_t lh
  * (bench.py: roofline.mfma_ceiling_measured). */
 int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void* stream);
 
+/* Calibration kernel: copies n_float4 16-byte words src -> dst (4096 workgroups, grid-stride, four loads in flight per lane);
+ * 2 * 16 * n_float4 bytes / time = the streaming HBM rate the GPU sustains (bench.py: roofline.hbm_ceiling_measured).  Use
+ * buffers well beyond the 256 MB Infinity Cache. */
+int premvos_hbm_copy_calibrate(const void* src, void* dst, int64_t n_float4, void* stream);
+
 /* Order-independent 64-bit digest of the 4-byte words of a pixel-major window [pixels][c] with pixel stride ps (words): the plan-time
  * tuner compares the outputs of configurations that must be bit-identical (same numerics key) before it lets a stopwatch choose
  * between them (premvos_amd/ops.py::_time_cands).  *out_u64 (device) receives the digest. */

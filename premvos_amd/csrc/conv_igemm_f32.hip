@@ -1083,6 +1083,28 @@ extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* 
 }
 
 namespace {
+// Calibration: a float4 copy (grid-stride, 16 bytes per lane and access, four independent loads in flight per thread) -- the HBM
+// rate this GPU sustains on a streaming read + write; bench.py reports it beside the MFMA calibration so that a line carries
+// its own box factor for the memory system too.
+__global__ __launch_bounds__(256) void hbm_copy_calibrate_kernel(const float4* __restrict__ src, float4* __restrict__ dst, const long n) {
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int premvos_hbm_copy_calibrate(const void* src, void* dst, int64_t n_float4, void* stream) {
+  PV_REQUIRE(src != nullptr && dst != nullptr && n_float4 > 0, "hbm_copy_calibrate: bad arguments");
+  hipLaunchKernelGGL(hbm_copy_calibrate_kernel, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float4*>(src), static_cast<float4*>(dst), (long)n_float4);
+  return premvos::check_launch("hbm_copy_calibrate");
+}
+
+namespace {
 // order-independent 64-bit digest of a strided pixel-major window: sum over (pixel, channel) of word * (2 * position + 1)
 __global__ __launch_bounds__(256) void digest_kernel(const unsigned* __restrict__ p, const long pixels, const int c, const int ps,
                                                      unsigned long long* out) {
@@ -1110,4 +1132,4 @@ extern "C" int premvos_digest_u64(const void* buf, int64_t pixels, int32_t c, in
   return premvos::check_launch("digest");
 }
 
-extern "C" int premvos_abi_version(void) { return 14; }   // bump with every change of include/premvos_hip.h
+extern "C" int premvos_abi_version(void) { return 15; }   // bump with every change of include/premvos_hip.h

@@ -165,6 +165,7 @@ class ResultExchange:
         self._work = [None] * slots
         self._send = [None] * slots
         self._n = 0
+        self.wait_s = 0.0          # seconds this rank spent blocked in wait() / flush() (bench.py: per-rank scaling diagnostics)
         self._pack_bits, self._unpack_bits = pack_bits or _hip_pack_bits, unpack_bits or _hip_unpack_bits
 
     def pack(self, r, slot: int = 0) -> torch.Tensor:
@@ -209,7 +210,10 @@ class ResultExchange:
     def wait(self, slot: int):
         w, self._work[slot] = self._work[slot], None
         if w is not None:
+            import time
+            t = time.perf_counter()
             w.wait()
+            self.wait_s += time.perf_counter() - t
 
     def flush(self):
         for s in range(len(self._work)):

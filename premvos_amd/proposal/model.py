@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, arena, ops
 from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, NHWC
 
 RESNET_NUM_BLOCK = (3, 4, 23, 3)           # config.py:61
@@ -66,24 +66,34 @@ class _Plan:
     def __init__(self, net: "ProposalNet", b: int, h: int, w: int):
         dev = net.device
         self.b, self.h, self.w = b, h, w
+        # activation memory by liveness (premvos_amd/arena.py): the launch list is built twice -- shapes and lifetimes, then on
+        # the packed arena (the bottleneck chain of a ResNet group rotates through the bytes of a handful of tensors)
+        self.arena = arena.two_pass(dev, lambda A: self._build(net, b, h, w, A))
+        self.ws_splitk = ops.assign_workspace(ops.autotune(self.tune_descs, dev) or self.tune_descs, dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _build(self, net: "ProposalNet", b: int, h: int, w: int, A: "arena.Arena"):
+        dev = net.device
         P, lib = net.packed, _lib.load()
         steps: List = []
-        keep: List = []
         self.flops: Dict[str, float] = {}
         self.descs: List = []
 
         def alloc(n, hh, ww, c):
-            v = NHWC.alloc(n, hh, ww, c, dev)
-            keep.append(v)
-            return v
+            ps = (c + 3) // 4 * 4
+            return NHWC(A.alloc(n, hh, ww, ps, "f32", pooled=ps == c), c=c)
 
         S8 = net.packed_s8
         self.tune_descs: List = []     # the launches premvos_conv2d_f32 runs (ops.autotune configures these; S8 convs have one kernel)
 
         def alloc_s8(n, hh, ww, c):
-            v = NHWC.alloc_s8(n, hh, ww, c, dev)
-            keep.append(v)
-            return v
+            assert c % 8 == 0
+            return NHWC(A.alloc(n, hh, ww, c, "s8"), c=c, layout="s8")
+
+        def release(*vs):              # the last launch that reads these tensors has been appended
+            for v in vs:
+                if v is not None:
+                    A.release(v.buf)
 
         def conv(x, name, out, uid=None, out_s8=None, res_s8=None, **kw):
             """``x`` in the resident split layout S8 (bf16x3 mode) -> csrc/conv_bf16x3_s8.hip (fp32 ``out`` and / or S8 ``out_s8``;
@@ -119,6 +129,7 @@ class _Plan:
             _lib.check(lib.premvos_maxpool_f32(i.ptr, i.ps, i.n, i.h, i.w, i.c, o.ptr, o.ps, o.h, o.w, 3, 2, 0, 0,
                                                0.0, _lib.current_stream()), "maxpool")
         steps.append(("maxpool", pool))
+        release(c0)
 
         def group(x: Optional[NHWC], g: int, feat: int, count: int, stride: int, tag: str = "", x8: Optional[NHWC] = None,
                   last_s8: bool = False, last_f32: bool = True):
@@ -131,12 +142,14 @@ class _Plan:
             s8 = net.s8 and g >= net.s8_from
             shape = (x if x is not None else x8)
             n_, h_, w_, c_ = shape.n, shape.h, shape.w, shape.c
+            own_x = own_x8 = False     # the group's own input belongs to the caller
             for i in range(count):
                 p = f"group{g}/block{i}"
                 s = stride if i == 0 else 1
                 last = i + 1 == count
                 if s8 and x8 is None:                   # entry of the chain: one split pass over the fp32 tensor
                     x8 = alloc_s8(n_, h_, w_, c_)
+                    own_x8 = True
                     steps.append((f"split8:{tag}{p}", lambda i_=x, o_=x8: ops.split8(i_, o_)))
                 xin = x8 if s8 else x
                 mk = alloc_s8 if s8 else alloc
@@ -163,21 +176,28 @@ class _Plan:
                 y = alloc(n_, ho, wo, feat * 4) if want_f32 else None
                 y8 = alloc_s8(n_, ho, wo, feat * 4) if s8 and (not last or last_s8) else None
                 conv(t2, p + "/conv3", y, uid=tag + p + "/conv3", out_s8=y8, res=res, res_s8=res8, act=ACT_RELU)     # relu(bn(conv3) + shortcut)
-                x, x8, h_, w_, c_ = y, y8, ho, wo, feat * 4
+                # the block's input, its two inner tensors and a convshortcut's output are dead now
+                release(t1, t2, res if res is not x else None, x if own_x else None, x8 if own_x8 else None)
+                x, x8, h_, w_, c_, own_x, own_x8 = y, y8, ho, wo, feat * 4, True, True
             return x, x8
 
         nb = net.num_blocks
         s8g = [net.s8 and g >= net.s8_from for g in range(4)]
-        x, x8 = group(x, 0, 64, nb[0], 1, last_s8=s8g[1], last_f32=not s8g[1])
-        x, x8 = group(x, 1, 128, nb[1], 2, x8=x8, last_s8=s8g[2], last_f32=not s8g[2])
-        fm, fm8 = group(x, 2, 256, nb[2], 2, x8=x8, last_s8=net.s8 and net.s8_rpn)
+        x1, x18 = group(x, 0, 64, nb[0], 1, last_s8=s8g[1], last_f32=not s8g[1])
+        release(x)
+        x2, x28 = group(x1, 1, 128, nb[1], 2, x8=x18, last_s8=s8g[2], last_f32=not s8g[2])
+        release(x1, x18)
+        fm, fm8 = group(x2, 2, 256, nb[2], 2, x8=x28, last_s8=net.s8 and net.s8_rpn)
+        release(x2, x28)
         self.featuremap = fm
         fh, fw = fm.h, fm.w
         # rpn_head (model.py:30-51): 3x3 + ReLU, then class(15) + box(60) as one 1x1 conv
         hid = alloc(b, fh, fw, 1024)
         conv(fm8 if fm8 is not None else fm, "rpn/conv0", hid, pad=(1, 1), act=ACT_RELU)
+        release(fm8)
         self.rpn_out = alloc(b, fh, fw, 5 * NUM_ANCHOR)
         conv(hid, "rpn/heads", self.rpn_out)
+        release(hid)
         R = TEST_POST_NMS_TOPK
         self.rois = torch.zeros((b, R, 4), dtype=torch.float32, device=dev)
         self.roi_scores = torch.zeros((b, R), dtype=torch.float32, device=dev)
@@ -193,7 +213,6 @@ class _Plan:
                 _lib.current_stream()), "rpn_proposals")
         steps.append(("rpn_proposals", rpn))
         roi = alloc(b * R, 14, 14, 1024)
-        self.roi_feat = roi
 
         def ralign(o=roi):
             _lib.check(lib.premvos_roi_align_f32(fm.ptr, fm.ps, b, fh, fw, 1024, self.rois.data_ptr(),
@@ -201,6 +220,7 @@ class _Plan:
                                                  _lib.current_stream()), "roi_align")
         steps.append(("roi_align", ralign))
         f5, _ = group(roi, 3, 512, nb[3], 2)         # resnet_conv5 (basemodel.py:92-99)
+        release(roi)
         self.feat5 = f5
         gp = alloc(b * R, 1, 1, 2048)
 
@@ -208,6 +228,7 @@ class _Plan:
             _lib.check(lib.premvos_global_avgpool_f32(i.ptr, i.ps, i.n, i.h * i.w, i.c, o.ptr, o.ps,
                                                       _lib.current_stream()), "gap")
         steps.append(("global_avgpool", gap))
+        # (f5, gp, the head logits and the feature map stay to the end of the list: drivers and tests read them after a run)
         nh = NUM_CLASS + 4 * (NUM_CLASS - 1) + SECOND_NUM_CLASS
         self.head = alloc(b * R, 1, 1, nh)
         conv(gp, "heads", self.head)
@@ -236,13 +257,14 @@ class _Plan:
                                                      o.ps, _lib.current_stream()), "roi_align(mask)")
             steps.append(("roi_align_mask", malign))
             mf5, _ = group(mroi, 3, 512, nb[3], 2, tag="mask:")   # the SAME conv5 weights (auto_reuse_variable_scope)
+            release(mroi)
             up = alloc(b * M, 14, 14, 256)
             conv(mf5, "maskrcnn/deconv", up, act=ACT_RELU)
+            release(mf5)
             self.final_masks = alloc(b * M, 14, 14, NUM_CLASS - 1)
             conv(up, "maskrcnn/conv", self.final_masks, act=ACT_SIGMOID)
-        self.steps, self.buffers = steps, keep
-        self.ws_splitk = ops.assign_workspace(ops.autotune(self.tune_descs, dev) or self.tune_descs, dev)
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+            release(up)
+        self.steps = steps
 
     def run(self, steps=None):
         for _, fn in (self.steps if steps is None else steps):

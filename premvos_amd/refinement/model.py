@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from .. import _lib, ops
+from .. import _lib, arena, ops
 from ..ops import ACT_NONE, ACT_RELU, NHWC
 
 INPUT_SIZE = 385
@@ -78,8 +78,18 @@ class _Plan:
         ``packed``: ``P`` is the TOTAL number of box slots of up to ``frames`` frames; which slots belong to which frame is
         set per call (``layout``: the boxes of a frame are a contiguous run), so a group of frames with 20, 23, 25 and 22
         proposals runs 96 crops, not 4 x 26 (eager launches only: the slot offsets are launch arguments)."""
-        dev, lib = net.device, _lib.load()
+        dev = net.device
         self.P, self.H, self.W, self.G, self.packed = P, H, W, frames, packed
+        # activation memory by liveness (premvos_amd/arena.py): the launch list is built twice -- shapes and lifetimes, then on
+        # the packed arena (up to round 4 same-SHAPE buffers were pooled: the 193 x 193 tensors of the entry flow, 15 GB of a
+        # 160-crop plan, sat idle for the rest of the list)
+        self.arena = arena.two_pass(dev, lambda A: self._build(net, P, H, W, with_posterior, frames, packed, A))
+        self.ws_splitk = ops.assign_workspace(ops.autotune(self.tune_descs, dev) or self.tune_descs, dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def _build(self, net: "RefinementNet", P: int, H: int, W: int, with_posterior: bool, frames: int, packed: bool,
+               A: "arena.Arena"):
+        dev, lib = net.device, _lib.load()
         G = frames
         PF = P if packed else P    # boxes per frame (packed: the whole slot range may belong to one frame)
         P = P if packed else G * PF    # batch of the network body
@@ -89,19 +99,14 @@ class _Plan:
         self.flops: Dict[str, float] = {}
         self.descs: List = []
         self.dw_bytes: Dict[str, float] = {}
-        pool: Dict[tuple, List[NHWC]] = {}
-        keep: List[NHWC] = []
 
         def alloc(n, h, w, c) -> NHWC:
-            key = (n, h, w, c)
-            if pool.get(key):
-                return pool[key].pop()
-            v = NHWC.alloc(n, h, w, c, dev)
-            keep.append(v)
-            return v
+            ps = (c + 3) // 4 * 4
+            return NHWC(A.alloc(n, h, w, ps, "f32", pooled=ps == c), c=c)
 
-        def release(v: NHWC):
-            pool.setdefault((v.n, v.h, v.w, v.c), []).append(v)
+        def release(v: Optional[NHWC]):                         # the last launch that reads ``v`` has been appended
+            if v is not None:
+                A.release(v.buf)
 
         # bf16x3 mode (round 4): the depthwise half of a separable conv stores its result in the resident split layout S8 (in place of
         # the floats: {hi8, lo8} per group of 8 channels) and the pointwise half runs on csrc/conv_bf16x3_s8.hip, which stages it by
@@ -111,16 +116,9 @@ class _Plan:
         S8 = net.packed_s8
         self.tune_descs: List = []     # the launches premvos_conv2d_f32 runs (ops.autotune configures these; S8 convs have one kernel)
 
-        def alloc_s8(n, h, w, c) -> NHWC:
-            key = (n, h, w, c, "s8")
-            if pool.get(key):
-                return pool[key].pop()
-            v = NHWC.alloc_s8(n, h, w, c, dev)
-            keep.append(v)
-            return v
-
-        def release(v: NHWC):                                   # (redefined: S8 buffers live in their own pool)
-            pool.setdefault((v.n, v.h, v.w, v.c) + (("s8",) if v.layout == "s8" else ()), []).append(v)
+        def alloc_s8(n, h, w, c) -> NHWC:                       # (S8 buffers live in an arena of their own)
+            assert c % 8 == 0
+            return NHWC(A.alloc(n, h, w, c, "s8"), c=c, layout="s8")
 
         def conv(x, name, out, out_s8=None, **kw):
             """``x`` in S8 -> the S8 kernel (fp32 ``out`` and / or S8 ``out_s8``); fp32 ``x`` -> premvos_conv2d_f32."""
@@ -246,12 +244,16 @@ class _Plan:
             i.ptr, i.ps, i.n, i.h * i.w, i.c, o.ptr, o.ps, _lib.current_stream()), "gap")))
         ip = alloc(P, 1, 1, 256)
         conv(gp, "image_pooling", ip, act=ACT_RELU)
+        release(gp)
         bc = alloc(P, fh, fh, 256) if cat8 else cat.slice(0, 256)
         steps.append(("broadcast", lambda i=ip, o=bc: _lib.check(lib.premvos_broadcast_pixel_f32(
             i.ptr, i.ps, i.n, 256, o.ptr, o.ps, o.h, o.w, _lib.current_stream()), "broadcast")))
+        release(ip)
         if cat8:       # the S8 concat buffer: the broadcast and the (fp32-input) 1x1 branch go through an fp32 block and are split once
             steps.append(("split8:image_pooling", lambda i=bc, o=cat.slice(0, 256): ops.split8(i, o)))
+            release(bc)
             conv(x8, "aspp0", None, cat.slice(256, 256), act=ACT_RELU)        # (x8: the S8 copy exit_flow's last conv wrote)
+            release(x8)
         else:
             conv(feat, "aspp0", cat.slice(256, 256), act=ACT_RELU)
         for i, r in enumerate(ATROUS_RATES, 1):
@@ -264,7 +266,8 @@ class _Plan:
             release(t)
         aspp = alloc(P, fh, fh, 256)
         conv(cat, "concat_projection", aspp, act=ACT_RELU)
-        self.aspp_out = aspp
+        release(cat)
+        self.aspp_out = aspp           # (named outputs -- xception_out, aspp_out, decoder_out, logits -- stay to the end of the list)
 
         # decoder (model.py:503-598): [aspp up-sampled (align_corners) | 1x1(skip) 48] -> 2 separable convs -> logits
         dh = int((float(S) - 1.0) * 0.25 + 1.0)                                   # scale_dimension
@@ -273,12 +276,15 @@ class _Plan:
         steps.append(("resize_aspp", lambda i=aspp, o=dcat.slice(0, 256): _lib.check(lib.premvos_resize_bilinear_f32(
             i.ptr, i.ps, i.n, i.h, i.w, 256, o.ptr, o.ps, o.h, o.w, 1, _lib.current_stream()), "resize")))
         conv(skip_feat, "decoder/feature_projection0", dcat.slice(256, 48), act=ACT_RELU)
+        release(skip_feat)
         d = dcat
         for j in (0, 1):
             t = alloc_mid(P, dh, dh, d.c, f"decoder/decoder_conv{j}_pointwise")
             dwconv(d, f"decoder/decoder_conv{j}_depthwise", t, act=ACT_RELU)
+            release(d)
             o = alloc(P, dh, dh, 256)
             conv(t, f"decoder/decoder_conv{j}_pointwise", o, act=ACT_RELU)
+            release(t)
             d = o
         self.decoder_out = d
         self.logits = alloc(P, dh, dh, 2)
@@ -309,9 +315,7 @@ class _Plan:
                     self.mask_g[g].data_ptr(), self.posterior_g[g].data_ptr() if with_posterior else None,
                     self.conf_g[g].data_ptr(), self.ws.data_ptr(), _lib.current_stream()), "refine_output")
         steps.append(("refine_output", out_layer))
-        self.steps, self.buffers = steps, keep
-        self.ws_splitk = ops.assign_workspace(ops.autotune(self.tune_descs, dev) or self.tune_descs, dev)
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.steps = steps
 
     def run(self, steps=None):
         for _, fn in (self.steps if steps is None else steps):

@@ -1,0 +1,88 @@
+"""premvos_amd.arena: liveness-planned activation memory of a launch plan (host logic; the GPU side is
+tests/test_gpu_arena.py)."""
+import random
+
+import pytest
+import torch
+
+from premvos_amd import arena
+
+
+def _check(items, offs, total):
+    al = lambda b: (b + arena.ALIGN - 1) // arena.ALIGN * arena.ALIGN      # noqa: E731
+    for i, (b, a, e) in enumerate(items):
+        assert offs[i] % arena.ALIGN == 0 and offs[i] + al(b) <= total
+        for j in range(i):
+            bj, aj, ej = items[j]
+            if aj < e and a < ej:                                          # live at the same time: disjoint bytes
+                assert offs[i] + al(b) <= offs[j] or offs[j] + al(bj) <= offs[i], (i, j)
+
+
+def test_pack_intervals_never_overlaps_live_tensors_and_reaches_the_chain_bound():
+    rng = random.Random(7)
+    for _ in range(50):
+        items = []
+        for _ in range(rng.randint(1, 60)):
+            a = rng.randint(0, 100)
+            items.append((rng.randint(1, 1 << 20), a, a + rng.randint(1, 30)))
+        offs, total = arena.pack_intervals(items)
+        _check(items, offs, total)
+        assert total <= sum((b + 255) // 256 * 256 for b, _, _ in items)
+    # a ResNet-like chain x -> t1 -> t2 -> y (y reads x as residual): four tensors live at most, whatever the depth
+    items, t = [], 0
+    big, small = 4 << 20, 1 << 20
+    x_alloc = 0
+    for blk in range(23):
+        items.append((small, t + 1, t + 7))        # t1
+        items.append((small, t + 2, t + 7))        # t2
+        items.append((big, t + 3, t + 17))         # y: live until the next block's conv3 has read it
+        t += 10
+    offs, total = arena.pack_intervals(items)
+    _check(items, offs, total)
+    assert total <= 2 * big + 2 * small + 4 * arena.ALIGN
+
+
+def test_two_pass_builder_reuses_bytes_and_keeps_unreleased_tensors(monkeypatch):
+    seen = {}
+
+    def build(A):
+        x = A.alloc(2, 8, 8, 16)
+        pad = A.alloc(2, 8, 8, 4, pooled=False)                # a tensor with padding channels: outside the arena
+        chain = []
+        for i in range(6):
+            y = A.alloc(2, 8, 8, 16)
+            chain.append(y)
+            A.release(x)
+            x = y
+        named = A.alloc(1, 4, 4, 8)                            # never released: live to the end
+        seen[A.dry] = (chain, named, pad, x)
+
+    A = arena.two_pass("cpu", build)
+    rep = A.report()
+    one = 4 * 2 * 8 * 8 * 16
+    assert rep["tensors"] == 8 and rep["one_buffer_per_tensor_bytes"] == 7 * one + 4 * 16 * 8
+    assert rep["arena_bytes"] <= 2 * one + 4 * 16 * 8 + 3 * arena.ALIGN          # two chain tensors live at a time + the named one
+    assert rep["arena_bytes"] >= rep["peak_live_bytes"]
+    chain, named, pad, last = seen[False]
+    assert all(t.device.type == "cpu" and t.shape == (2, 8, 8, 16) and float(t.abs().sum()) == 0.0 for t in chain)
+    assert chain[0].data_ptr() == chain[2].data_ptr() == chain[4].data_ptr() != chain[1].data_ptr()      # rotation
+    lo, hi = named.data_ptr(), named.data_ptr() + 4 * named.numel()
+    l2, h2 = last.data_ptr(), last.data_ptr() + 4 * last.numel()
+    assert hi <= l2 or h2 <= lo                                                   # both live at the end: disjoint
+    assert seen[True][0][0].device.type == "meta"
+    # switched off: one tensor per alloc, release is a no-op
+    monkeypatch.setenv("PREMVOS_ARENA", "0")
+    B = arena.two_pass("cpu", build)
+    chain = seen[False][0]
+    assert len({t.data_ptr() for t in chain}) == 6 and B.report()["arena_bytes"] == 0
+
+
+def test_diverging_passes_are_caught():
+    n = {"k": 0}
+
+    def build(A):
+        n["k"] += 1
+        A.alloc(1, 2, 2, 4 * n["k"])
+
+    with pytest.raises(AssertionError):
+        arena.two_pass("cpu", build)

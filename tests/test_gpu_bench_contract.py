@@ -26,7 +26,7 @@ def _run(extra_env, *args):
 def test_bench_line_through_the_distributed_path():
     d = _run({"PREMVOS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
               "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
-             "--scaling", "weak", "--no-cpu-baseline", "--file-to-file", "0")
+             "--scaling", "weak", "--no-cpu-baseline", "--file-to-file", "0", "--supplementary", "none")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -40,6 +40,13 @@ def test_bench_line_through_the_distributed_path():
     assert "workload" in d["config"] and "model" not in d["config"]
     assert "ONE" in d["config"]["parallelism"] and "gather" in d["config"]["parallelism"]
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+    # the line carries its own box factors: HBM copy rate, one canonical layer, clock / power over the timed region
+    assert 2000 < r["hbm_ceiling_measured"] < 8000 and r["canonical_layer"]["us"] > 0 and "728 -> 728" in r["canonical_layer"]["what"]
+    assert "error" in d["box"] or (d["box"]["samples"] >= 1 and 500 < d["box"]["sclk_mhz_mean_of_xcds"]["mean"] < 3000)
+    # ... and per-rank scaling diagnostics whenever a process group exists
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 1 and pr["rank_skew_ms_per_step"] == 0.0 and pr["exchange_wait_ms_per_step"][0] >= 0.0
+    assert pr["cold_start_s"][0] > 0 and d["cold_start_s"] == pr["cold_start_s"][0]
 
 
 def test_bench_launches_its_own_ranks():
@@ -98,4 +105,10 @@ def test_bench_strong_scaling_eight_ranks_with_a_ragged_video():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["frames_per_step"] == 13
     assert abs(d["value"] - 13 * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]
+    # per-rank scaling diagnostics: one entry per rank, the chunk-less rank launches nothing
+    pr = d["per_rank"]
+    assert all(len(pr[k]) == 8 for k in ("ms_per_step", "launches_per_step", "exchange_wait_ms_per_step", "cold_start_s"))
+    assert sorted(pr["launches_per_step"]) == [0, 1, 1, 1, 1, 1, 1, 1] and sum(pr["launches_per_step"]) == 7
+    assert pr["rank_skew_ms_per_step"] == round(max(pr["ms_per_step"]) - min(pr["ms_per_step"]), 3) and 0 <= pr["slowest_rank"] < 8
+    assert max(pr["ms_per_step"]) <= d["ms_per_step"] * 1.001 and all(w >= 0 for w in pr["exchange_wait_ms_per_step"])
     assert d["conv_configurations"]["signatures_explored_by_time"] == 0
