@@ -319,7 +319,7 @@ int premvos_refine_output_f32(const float* logits, int32_t logits_ps, int32_t lh
  * (bench.py: roofline.mfma_ceiling_measured). */
 int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void* stream);
 
-/* Calibration kernel: copies n_float4 16-byte words src -> dst (4096 workgroups, grid-stride, four loads in flight per lane);
+/* Calibration kernel: copies n_float4 16-byte words src -> dst (one word per thread, flat grid);
  * 2 * 16 * n_float4 bytes / time = the streaming HBM rate the GPU sustains (bench.py: roofline.hbm_ceiling_measured).  Use
  * buffers well beyond the 256 MB Infinity Cache. */
 int premvos_hbm_copy_calibrate(const void* src, void* dst, int64_t n_float4, void* stream);

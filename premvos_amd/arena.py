@@ -104,8 +104,12 @@ class Arena:
                 self.items[i][2] = self.tick
 
     # -- between the passes ------------------------------------------------------------------------------------------
-    def packed(self) -> "Arena":
-        """The real arena for pass 2."""
+    def packed(self, shared: Optional[dict] = None) -> "Arena":
+        """The real arena for pass 2.  ``shared`` (kind -> tensor, updated in place): plans that never execute concurrently and
+        run stream-ordered one after the other (the refinement plans of ONE lane: one per packed slot count / frame group) live in
+        the same bytes -- a plan takes the shared buffer when it is large enough, else a new one that replaces it for later plans
+        (the earlier plans keep theirs).  A plan reads nothing it has not written in the same run, so whatever another plan left
+        in the buffer never reaches a result."""
         assert self.dry
         real = Arena(self.device, dry=False)
         end = self.tick + 1
@@ -117,7 +121,12 @@ class Arena:
             for i, o in zip(idx, offs):
                 real.offsets[i] = o
             real.sizes[kind] = total
-            real.bufs[kind] = torch.zeros(total // 4, dtype=torch.float32, device=self.device)
+            buf = shared.get(kind) if shared is not None else None
+            if buf is None or buf.numel() * 4 < total:
+                buf = torch.zeros(total // 4, dtype=torch.float32, device=self.device)
+                if shared is not None:
+                    shared[kind] = buf
+            real.bufs[kind] = buf
         return real
 
     def report(self) -> dict:
@@ -132,11 +141,11 @@ class Arena:
                 "tensors": len(self.items), "outside_bytes": sum(4 * t.numel() for t in self.loose)}
 
 
-def two_pass(device, build):
+def two_pass(device, build, shared: Optional[dict] = None):
     """``build(arena)`` twice: shapes and lifetimes, then the real thing.  Returns the real arena."""
     dry = Arena(device, dry=True)
     build(dry)
-    real = dry.packed()
+    real = dry.packed(shared)
     build(real)
     assert real.cursor == len(real.items), "the plan builder's two passes diverged"
     return real

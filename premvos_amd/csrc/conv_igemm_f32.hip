@@ -1083,23 +1083,19 @@ extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* 
 }
 
 namespace {
-// Calibration: a float4 copy (grid-stride, 16 bytes per lane and access, four independent loads in flight per thread) -- the HBM
-// rate this GPU sustains on a streaming read + write; bench.py reports it beside the MFMA calibration so that a line carries
-// its own box factor for the memory system too.
+// Calibration: a float4 copy, ONE 16-byte word per thread on a flat grid of n / 256 workgroups -- the HBM rate this GPU sustains on
+// a streaming read + write (6.1 TB/s; the same copy as a grid-stride loop of 4096 persistent workgroups with four loads in flight
+// reaches only 4.3, non-temporal accesses 6.5: tools/dev/hbm_copy_variants.hip).  bench.py reports it beside the MFMA calibration so
+// that a line carries its own box factor for the memory system too.
 __global__ __launch_bounds__(256) void hbm_copy_calibrate_kernel(const float4* __restrict__ src, float4* __restrict__ dst, const long n) {
-  const long stride = (long)gridDim.x * 256;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-  }
-  for (; i < n; i += stride) dst[i] = src[i];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
 }
 }  // namespace
 
 extern "C" int premvos_hbm_copy_calibrate(const void* src, void* dst, int64_t n_float4, void* stream) {
-  PV_REQUIRE(src != nullptr && dst != nullptr && n_float4 > 0, "hbm_copy_calibrate: bad arguments");
-  hipLaunchKernelGGL(hbm_copy_calibrate_kernel, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+  PV_REQUIRE(src != nullptr && dst != nullptr && n_float4 > 0 && n_float4 < (1LL << 38), "hbm_copy_calibrate: bad arguments");
+  hipLaunchKernelGGL(hbm_copy_calibrate_kernel, dim3((unsigned)((n_float4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float4*>(src), static_cast<float4*>(dst), (long)n_float4);
   return premvos::check_launch("hbm_copy_calibrate");
 }

@@ -377,6 +377,109 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
   }
 }
 
+// The same RoIAlign with one thread per (RoI, output ROW, 4 channels) that walks the row's 2 x 28 samples from left to right and
+// keeps the corner pixels of its four feature-map rows (top / bottom row of the two sample rows) in registers: a sample loads only
+// when its column pair moved on -- an object-sized box (100 px = 6 feature-map pixels wide) takes ~2 loads per output pixel instead
+// of 16, a frame-wide one ~8; the per-bin form above is bound by those loads (80 M 16-byte requests out of L2 / Infinity Cache for
+// 80 MB of output: 1.2 TB/s).  A wave = 64 channel groups of ONE (RoI, row): every branch below is wave-uniform.  Same sample
+// values (identical expressions) added in the same order: bit-identical to roi_align_kernel (tests/test_gpu_proposal.py).
+__global__ __launch_bounds__(256) void roi_align_row_kernel(const float* __restrict__ fm, int ps, int H, int W, int c4,
+                                                            const float* __restrict__ rois, const int* __restrict__ count,
+                                                            int rois_per_img, int n_img, float scale, int outsz,
+                                                            float* __restrict__ out, int out_ps) {
+  const long total = (long)n_img * rois_per_img * outsz * c4;
+  const int crop = 2 * outsz;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = idx % c4;
+    long t = idx / c4;
+    const int by_ = t % outsz;
+    const long r = t / outsz;
+    const int img = r / rois_per_img, rl = r % rois_per_img;
+    float* orow = out + ((r * outsz + by_) * outsz) * out_ps + cg * 4;
+    if (rl >= count[img]) {
+      for (int bx_ = 0; bx_ < outsz; ++bx_) *reinterpret_cast<float4*>(orow + (long)bx_ * out_ps) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const float* rb = rois + r * 4;
+    const float x0 = rb[0] * scale, y0 = rb[1] * scale, x1 = rb[2] * scale, y1 = rb[3] * scale;
+    const float sw = (x1 - x0) / (float)crop, sh = (y1 - y0) / (float)crop;
+    const float nx0 = (x0 + sw / 2.f - 0.5f) / (float)(W - 1), ny0 = (y0 + sh / 2.f - 0.5f) / (float)(H - 1);
+    const float nw = sw * (float)(crop - 1) / (float)(W - 1), nh = sh * (float)(crop - 1) / (float)(H - 1);
+    const float by1 = ny0, bx1 = nx0, by2 = ny0 + nh, bx2 = nx0 + nw;
+    const float hs = (by2 - by1) * (float)(H - 1) / (float)(crop - 1);
+    const float ws = (bx2 - bx1) * (float)(W - 1) / (float)(crop - 1);
+    const float* fb = fm + (long)img * H * W * ps + cg * 4;
+    bool oky[2];
+    float yl[2];
+    const float* rt[2];
+    const float* rbt[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float in_y = by1 * (float)(H - 1) + (float)(2 * by_ + j) * hs;
+      oky[j] = !(in_y < 0.f || in_y > (float)(H - 1));
+      const int yt = oky[j] ? (int)floorf(in_y) : 0, yb = oky[j] ? (int)ceilf(in_y) : 0;
+      yl[j] = in_y - floorf(in_y);
+      rt[j] = fb + (long)yt * W * ps;
+      rbt[j] = fb + (long)yb * W * ps;
+    }
+    // corner cache: [j][0] = top row, [j][1] = bottom row of sample row j; L = column cxl, R = column cxr
+    float4 L[2][2], R[2][2];
+    int cxl = -2, cxr = -2;
+    float4 sv[2][2];                       // sample values of the current bin: [j][i]
+    bool sok[2];
+    for (int bx_ = 0; bx_ < outsz; ++bx_) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {          // (static indices: sv / sok stay in registers)
+        const int sx = 2 * bx_ + i;
+        const float in_x = bx1 * (float)(W - 1) + (float)sx * ws;
+        const bool okx = !(in_x < 0.f || in_x > (float)(W - 1));
+        sok[i] = okx;
+        if (okx) {
+          const int xl = (int)floorf(in_x), xr = (int)ceilf(in_x);
+          const float xlp = in_x - floorf(in_x);
+          if (xl != cxl || xr != cxr) {
+            const bool shift = xl == cxr;                  // the old right column is the new left one
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (oky[j]) {
+                if (shift) { L[j][0] = R[j][0]; L[j][1] = R[j][1]; }
+                else {
+                  L[j][0] = *reinterpret_cast<const float4*>(rt[j] + (long)xl * ps);
+                  L[j][1] = *reinterpret_cast<const float4*>(rbt[j] + (long)xl * ps);
+                }
+                if (xr == xl) { R[j][0] = L[j][0]; R[j][1] = L[j][1]; }
+                else {
+                  R[j][0] = *reinterpret_cast<const float4*>(rt[j] + (long)xr * ps);
+                  R[j][1] = *reinterpret_cast<const float4*>(rbt[j] + (long)xr * ps);
+                }
+              }
+            cxl = xl; cxr = xr;
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (oky[j]) {
+              const float4 a = L[j][0], b = R[j][0], c = L[j][1], d = R[j][1];
+              float top, bot;
+              top = a.x + (b.x - a.x) * xlp; bot = c.x + (d.x - c.x) * xlp; sv[j][i].x = top + (bot - top) * yl[j];
+              top = a.y + (b.y - a.y) * xlp; bot = c.y + (d.y - c.y) * xlp; sv[j][i].y = top + (bot - top) * yl[j];
+              top = a.z + (b.z - a.z) * xlp; bot = c.z + (d.z - c.z) * xlp; sv[j][i].z = top + (bot - top) * yl[j];
+              top = a.w + (b.w - a.w) * xlp; bot = c.w + (d.w - c.w) * xlp; sv[j][i].w = top + (bot - top) * yl[j];
+            }
+        }
+      }
+      // the bin is complete: add its samples in the per-bin kernel's order (j, then i)
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+          if (oky[j] && sok[ii]) { acc.x += sv[j][ii].x; acc.y += sv[j][ii].y; acc.z += sv[j][ii].z; acc.w += sv[j][ii].w; }
+      acc.x *= 0.25f; acc.y *= 0.25f; acc.z *= 0.25f; acc.w *= 0.25f;
+      *reinterpret_cast<float4*>(orow + (long)bx_ * out_ps) = acc;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Global average pool NHWC [n][hw][c] -> [n][c]  (GlobalAvgPooling, model.py:387, 561)
 __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ in, int in_ps, int n, int hw, int c4,
@@ -504,7 +607,9 @@ __global__ __launch_bounds__(TAIL_NT) void frcnn_tail_kernel(const TailArgs p) {
   }
 }
 
-inline int grid_for(long total, int per_block = 256, int cap = 256 * 16) {
+// (round 5: a FLAT grid -- one item per thread -- moves 6.1 TB/s where a grid-stride loop over 4 ... 8 k resident workgroups moves 4.3 ... 4.7,
+// tools/dev/hbm_copy_variants.hip; the cap only bounds the grid dimension)
+inline int grid_for(long total, int per_block = 256, int cap = 1 << 22) {
   long g = (total + per_block - 1) / per_block;
   return (int)(g < 1 ? 1 : g > cap ? cap : g);
 }
@@ -564,10 +669,19 @@ extern "C" int premvos_roi_align_f32(const float* fmap, int32_t fmap_ps, int32_t
   PV_REQUIRE(c % 4 == 0 && fmap_ps % 4 == 0 && out_ps % 4 == 0 && fmap_ps >= c && out_ps >= c,
              "roi_align: C and pixel strides must be multiples of 4");
   PV_REQUIRE(premvos::aligned16(fmap) && premvos::aligned16(out), "roi_align: fmap/out must be 16-byte aligned");
-  const long total = (long)n_img * rois_per_img * out_size * out_size * (c / 4);
-  hipLaunchKernelGGL(roi_align_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), fmap, fmap_ps, h, w, c / 4, rois, count, rois_per_img, n_img,
-                     spatial_scale, out_size, out, out_ps);
+  // PREMVOS_ROI_ALIGN=bin: the per-bin kernel (developer A/B; both give the same bits)
+  static const bool per_bin = [] { const char* e = getenv("PREMVOS_ROI_ALIGN"); return e != nullptr && e[0] == 'b'; }();
+  if (per_bin) {
+    const long total = (long)n_img * rois_per_img * out_size * out_size * (c / 4);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(grid_for(total)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), fmap, fmap_ps, h, w, c / 4, rois, count, rois_per_img, n_img,
+                       spatial_scale, out_size, out, out_ps);
+  } else {
+    const long total = (long)n_img * rois_per_img * out_size * (c / 4);
+    hipLaunchKernelGGL(roi_align_row_kernel, dim3(grid_for(total)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), fmap, fmap_ps, h, w, c / 4, rois, count, rois_per_img, n_img,
+                       spatial_scale, out_size, out, out_ps);
+  }
   return premvos::check_launch("roi_align");
 }
 

@@ -72,7 +72,7 @@ class PackedDW:
 
 class _Plan:
     def __init__(self, net: "RefinementNet", P: int, H: int, W: int, with_posterior: bool, frames: int = 1,
-                 packed: bool = False):
+                 packed: bool = False, lane: int = 0):
         """One launch list for ``frames`` frames x ``P`` boxes each: the crops of all frames form ONE batch of the network
         (bigger GEMM M -> fewer partly filled waves of tiles); crop extraction and un-cropping run per frame.
         ``packed``: ``P`` is the TOTAL number of box slots of up to ``frames`` frames; which slots belong to which frame is
@@ -83,7 +83,10 @@ class _Plan:
         # activation memory by liveness (premvos_amd/arena.py): the launch list is built twice -- shapes and lifetimes, then on
         # the packed arena (up to round 4 same-SHAPE buffers were pooled: the 193 x 193 tensors of the entry flow, 15 GB of a
         # 160-crop plan, sat idle for the rest of the list)
-        self.arena = arena.two_pass(dev, lambda A: self._build(net, P, H, W, with_posterior, frames, packed, A))
+        # ... and the plans of one lane (one per packed slot count / group of frames; a lane runs one plan at a time, stream-ordered)
+        # share the lane's bytes
+        self.arena = arena.two_pass(dev, lambda A: self._build(net, P, H, W, with_posterior, frames, packed, A),
+                                    shared=net._lane_bytes.setdefault(lane, {}) if arena.enabled() else None)
         self.ws_splitk = ops.assign_workspace(ops.autotune(self.tune_descs, dev) or self.tune_descs, dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
 
@@ -349,6 +352,7 @@ class RefinementNet:
         self.packed_s8: Dict[str, ops.PackedConvS8] = {}     # bf16x3 mode: the convs whose input is resident in the S8 layout
         self.packed_dw: Dict[str, PackedDW] = {}
         self._plans: Dict[tuple, _Plan] = {}
+        self._lane_bytes: Dict[int, dict] = {}       # lane -> {arena kind: the activation bytes its plans share}
         self._plans_lock = __import__("threading").Lock()
         self.max_plans = int(os.environ.get("PREMVOS_REFINE_MAX_PLANS", "12"))
         head = ("image_pooling", "aspp", "concat_projection", "decoder/")
@@ -389,7 +393,7 @@ class RefinementNet:
             with self._plans_lock:                # graph capture of a plan is done by one of them at a time
                 p = self._plans.get(key)
             if p is None:
-                p = _Plan(self, P, H, W, with_posterior, frames, packed)
+                p = _Plan(self, P, H, W, with_posterior, frames, packed, lane)
                 if self.use_graph and not packed:
                     torch.cuda.synchronize()      # capture must not race kernels of another lane's stream
                     p.capture()

@@ -86,3 +86,23 @@ def test_diverging_passes_are_caught():
 
     with pytest.raises(AssertionError):
         arena.two_pass("cpu", build)
+
+
+def test_plans_of_one_lane_share_their_bytes():
+    def builder(n):
+        def build(A):
+            x = A.alloc(n, 4, 4, 8)
+            y = A.alloc(n, 4, 4, 8)
+            A.release(x)
+            build.out = (x, y)
+        return build
+
+    lane = {}
+    b8, b4, b16 = builder(8), builder(4), builder(16)
+    a8 = arena.two_pass("cpu", b8, shared=lane)
+    big = lane["f32"]
+    a4 = arena.two_pass("cpu", b4, shared=lane)                 # a smaller plan of the lane lives in the same bytes
+    assert lane["f32"] is big and a4.bufs["f32"] is big and b4.out[0].data_ptr() == b8.out[0].data_ptr()
+    a16 = arena.two_pass("cpu", b16, shared=lane)               # a larger one replaces the lane's buffer; the earlier plans keep theirs
+    assert lane["f32"] is a16.bufs["f32"] and a16.bufs["f32"] is not big and a8.bufs["f32"] is big
+    assert a16.bufs["f32"].numel() * 4 >= a16.report()["peak_live_bytes"]
