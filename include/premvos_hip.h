@@ -97,6 +97,8 @@ typedef struct premvos_conv_desc {
                         /*     (3x3 / stride 1; atrous layers with dilation d = pad run as d x d interleaved sub-lattices)      */
                         /* 5 = short-K pointwise layers (1x1, stride 1, cin = 64 | 128 = k_pad, cout % 128 == 0, <= 512):   */
                         /* persistent workgroups, weights resident in LDS (csrc/conv_stream_f32.hip); the implicit GEMM's sums */
+                        /* 6 = pointwise layers (1x1, no padding, any stride, k_pad >= 32, cout % 4 == 0, 16-byte aligned pixels): */
+                        /* 128 x 128 tiles with both operands staged by LDS-DMA (csrc/conv_pwdma_f32.hip); the implicit GEMM's sums */
   int32_t split_k;      /* 0 = auto, <0 = never, >0 = force this many k-slices */
   float* workspace;     /* split-K partial slabs (may be NULL: then never split) */
   int64_t workspace_bytes;

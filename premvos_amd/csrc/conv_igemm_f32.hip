@@ -112,6 +112,7 @@ __global__ __launch_bounds__(64 * WM * WN, occ_of(BM, BN, WM, WN, PIXSHUF)) void
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-thread gather state -------------------------------------------------------------
+  [[maybe_unused]] const bool pw_unit = p.sh == 1 && p.sw == 1 && p.ho == p.h && p.wo == p.w;
   const int j4 = (tid % KU) * 4;  // this thread's float4 column inside the KB-deep stage
   const float* rowbase[A_PER_T];
   int iy0[A_PER_T], ix0[A_PER_T];
@@ -121,6 +122,15 @@ __global__ __launch_bounds__(64 * WM * WN, occ_of(BM, BN, WM, WN, PIXSHUF)) void
     const int m = m0 + row;
     const bool ok = (row < BM) && (m < M);
     const int mm = ok ? m : 0;
+    if constexpr (PW) {
+      // round 5: a unit-stride pointwise layer reads pixel m of the input -- no (image, y, x) split, i.e. none of the two integer
+      // divisions per row that made the address arithmetic most of a tile's prologue (profiles/r05_timeline_igemm.txt: 8 us)
+      if (pw_unit) {                               // kernel-uniform
+        rowbase[i] = ok ? p.in + (long)mm * p.in_ps : nullptr;
+        iy0[i] = ix0[i] = 0;
+        continue;
+      }
+    }
     const int hw = p.ho * p.wo;
     const int n = mm / hw, rem = mm - n * hw;
     const int oy = rem / p.wo, ox = rem - oy * p.wo;
@@ -776,6 +786,8 @@ long conv_wino4_workspace_bytes(const premvos_conv_desc& d);
 int conv_wino4(const premvos_conv_desc& d, hipStream_t s);
 bool conv_stream_applicable(const premvos_conv_desc& d);      // conv_stream_f32.hip
 int conv_stream(const premvos_conv_desc& d, hipStream_t s);
+bool conv_pwdma_applicable(const premvos_conv_desc& d);       // conv_pwdma_f32.hip
+int conv_pwdma(const premvos_conv_desc& d, hipStream_t s);
 bool conv_smalln_applicable(const premvos_conv_desc& d);      // conv_smalln_f32.hip
 int conv_smalln(const premvos_conv_desc& d, hipStream_t s);
 int launch_splitk_reduce(const premvos_conv_desc& d, int splits, int ncols, hipStream_t s, int m_begin) {
@@ -990,6 +1002,11 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
                "(= k_pad), cout %% 128 == 0 (<= 512) and 16-byte aligned pixels");
     return premvos::conv_stream(d, s);
   }
+  if (d.tile_hint == 6) {      // pointwise layers, operands staged by LDS-DMA (conv_pwdma_f32.hip); same sums as the implicit GEMM
+    PV_REQUIRE(premvos::conv_pwdma_applicable(d), "conv2d: the LDS-DMA pointwise kernel needs a 1x1 fp32 layer without padding, k_pad >= 32, "
+               "cout %% 4 == 0 and 16-byte aligned pixels");
+    return premvos::conv_pwdma(d, s);
+  }
   // 1- and 2-channel heads: per-pixel dot products, not GEMM tiles (tile_hint 0 = auto, 1 = forced; any other hint
   // keeps them on the MFMA kernel, which is what the autotuner compares against)
   if ((d.tile_hint == 0 || d.tile_hint == 1) && premvos::conv_smalln_applicable(d)) return premvos::conv_smalln(d, s);
@@ -1027,7 +1044,7 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   if (dp->tile_hint == 2) return premvos::conv_wino_applicable(*dp) ? premvos::conv_wino_workspace_bytes(*dp) : 0;
   if (dp->tile_hint == 3) return 0;
   if (dp->tile_hint == 4) return premvos::conv_wino4_applicable(*dp) ? premvos::conv_wino4_workspace_bytes(*dp) : 0;
-  if (dp->tile_hint == 5) return 0;
+  if (dp->tile_hint == 5 || dp->tile_hint == 6) return 0;
   if ((dp->tile_hint == 0 || dp->tile_hint == 1) && premvos::conv_smalln_applicable(*dp)) return 0;
   int bm, bn;
   pick_tile(*dp, &bm, &bn);

@@ -306,6 +306,16 @@ def stream_applicable(d: ConvDesc) -> bool:
         and (d.inp or 0) % 16 == 0 and (d.out or 0) % 16 == 0 and (d.res or 0) % 16 == 0
 
 
+def pwdma_applicable(d: ConvDesc) -> bool:
+    """Mirror of premvos::conv_pwdma_applicable (csrc/conv_pwdma_f32.hip): 1x1 fp32 layers without padding, K of two stages or more,
+    the wide epilogue's alignment conditions."""
+    return d.precision == _lib.PREC_F32 and (d.kh, d.kw, d.pt, d.pl) == (1, 1, 0, 0) and d.out_mode == OUT_NHWC \
+        and d.ho == (d.h - 1) // d.sh + 1 and d.wo == (d.w - 1) // d.sw + 1 and d.k_pad >= 32 and d.k_pad % 16 == 0 and d.cin_pad % 4 == 0 \
+        and d.cin_pad <= d.k_pad and d.k_pad - d.cin_pad < 16 and d.in_ps >= d.cin_pad and d.cout % 4 == 0 and d.out_ps % 4 == 0 \
+        and d.in_ps % 4 == 0 and (d.inp or 0) % 16 == 0 and (d.out or 0) % 16 == 0 and (d.res or 0) % 16 == 0 \
+        and (not d.res or d.res_ps % 4 == 0) and (d.bias or 0) % 16 == 0
+
+
 def _candidates(d: ConvDesc):
     m = d.n * d.ho * d.wo
     if d.cout <= 32:
@@ -340,6 +350,8 @@ def _candidates(d: ConvDesc):
             out.extend((4, v, -1, 0, 0) for v in (0, 64, 16, 80))     # GEMM block: 128 / 64 tile rows x 32- / 16-deep stages
     if stream_applicable(d):
         out.append((5, 0, -1, 0, 0))               # tile_hint 5 = short-K streaming pointwise kernel (csrc/conv_stream_f32.hip): same sums
+    if pwdma_applicable(d) and d.cout > 64 and os.environ.get("PREMVOS_PWDMA", "1") != "0":
+        out.append((6, 0, -1, 0, 0))               # tile_hint 6 = LDS-DMA staged pointwise kernel (csrc/conv_pwdma_f32.hip): same sums
     for bm, bn in tiles:
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((256, 128), (128, 128), (128, 64), (64, 128))) else [16]
@@ -431,7 +443,7 @@ def numerics_key(d: ConvDesc, cand):
     hint, st, sk, tail_rows, ts = cand
     if hint in (1, 2, 3, 4):
         return (hint,)
-    if hint == 5:                                # the streaming pointwise kernel adds the products in the implicit GEMM's order
+    if hint in (5, 6):                           # the streaming / LDS-DMA pointwise kernels add the products in the implicit GEMM's order
         return (0, None, None)
     bm = hint >> 16
     m = d.n * d.ho * d.wo
@@ -482,7 +494,7 @@ def _entry_for(d: ConvDesc):
     Winograd candidates withheld -- instead of failing in the library's argument check at launch time."""
     cand = _TUNE_CACHE[_sig(d)]
     hint = cand[0]
-    if hint == 5 and not stream_applicable(d):
+    if (hint == 5 and not stream_applicable(d)) or (hint == 6 and not pwdma_applicable(d)):
         return ((128 << 16) | 128, 16, -1, 0, 0)
     if hint in (2, 3, 4) and cand not in _candidates(d):
         w2, w4, d.wgt_wino, d.wgt_wino4 = d.wgt_wino, d.wgt_wino4, None, None

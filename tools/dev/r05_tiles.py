@@ -5,11 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from premvos_amd import ops, _lib
 import ctypes as C
 lib, st = _lib.load(), _lib.current_stream()
-TILES = [("128x128", (128 << 16) | 128), ("256x128w8", (256 << 16) | 128), ("128x256", (128 << 16) | 256),
+TILES = [("128x128", (128 << 16) | 128), ("pwdma", 6), ("256x128w8", (256 << 16) | 128), ("128x256", (128 << 16) | 256),
          ("256x128w4", (256 << 16) | 129), ("256x256w8", (256 << 16) | 256)]
 SHAPES = [("sweep K=256", 96, 32, 32, 256, 768), ("sweep K=768", 96, 32, 32, 768, 768), ("sweep K=1024", 96, 32, 32, 1024, 768),
           ("sweep K=3072", 96, 32, 32, 3072, 768), ("mid 728->728", 160, 25, 25, 728, 728), ("exit 1536->2048", 160, 25, 25, 1536, 2048),
-          ("res 1024->256", 16, 47, 84, 1024, 256)]
+          ("res 1024->256", 16, 47, 84, 1024, 256), ("res 256->1024", 16, 47, 84, 256, 1024), ("entry 256->256", 160, 97, 97, 256, 256),
+          ("entry 256->728", 160, 49, 49, 256, 728), ("exit 1024->1536", 160, 25, 25, 1024, 1536)]
+if len(sys.argv) > 1 and sys.argv[1] == "dma":
+    TILES = TILES[:2]
 for name, n, h, w, cin, cout in SHAPES:
     x = ops.NHWC(torch.randn((n, h, w, (cin + 3) // 4 * 4), device="cuda"), c=cin)
     pk = ops.pack_conv(torch.randn((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5, torch.randn(cout) * 0.1)
