@@ -454,6 +454,8 @@ class DeviceGather:
         self.hm, self.wm = hm, wm
         self.x = ResultExchange(pipe.batch, hm, wm, self.P, device, pack_bits=pack_bits, unpack_bits=unpack_bits)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:      # taken on the constructing (main) thread: the exchange thread
+            self.device = torch.device("cuda", torch.cuda.current_device())   # selects THIS device, whatever its own default is
 
     def staging(self) -> dict:
         """The ``r`` dict of one chunk (ResultExchange.pack's input), zero-filled, at the job's largest frame size."""
