@@ -1025,9 +1025,10 @@ extern "C" int premvos_conv2d_f32(const premvos_conv_desc* dp, void* stream) {
   switch ((bm << 16) | bn) {
     case (256 << 16) | 128: return launch_cfg<256, 128, 4, 2>(d, s);      // 8 waves of 64x64: half the B staging per MFMA
     case (128 << 16) | 128: return launch_cfg<128, 128, 2, 2>(d, s);
-    case (128 << 16) | 256: return launch_cfg<128, 256, 2, 2>(d, s);      // 4 waves of 64x128
-    case (256 << 16) | 129: return launch_cfg<256, 128, 2, 2>(d, s);      // 4 waves of 128x64 (hint 256x129)
-    case (256 << 16) | 256: return launch_cfg<256, 256, 4, 2>(d, s);      // 8 waves of 64x128
+    // four waves of 128 x 64 (hint 256x129; round 5): half the A fragment reads per MFMA of the 2 x 2 layout's B side, two workgroups
+    // per CU -- wins short-K layers with few column tiles (profiles/r05_wave_tile_ab.txt; the 128 x 256 / 256 x 256 developer tiles of
+    // that A/B lost on every layer of the nets and were removed)
+    case (256 << 16) | 129: return launch_cfg<256, 128, 2, 2>(d, s);
     case (128 << 16) | 96: return launch_cfg<128, 96, 4, 1>(d, s);
     case (128 << 16) | 64: return launch_cfg<128, 64, 2, 2>(d, s);
     case (128 << 16) | 32: return launch_cfg<128, 32, 4, 1>(d, s);
@@ -1051,9 +1052,7 @@ extern "C" int64_t premvos_conv2d_workspace_bytes(const premvos_conv_desc* dp) {
   switch ((bm << 16) | bn) {
     case (256 << 16) | 128: return ws_cfg<256, 128, 4, 2>(*dp);
     case (128 << 16) | 128: return ws_cfg<128, 128, 2, 2>(*dp);
-    case (128 << 16) | 256: return ws_cfg<128, 256, 2, 2>(*dp);
     case (256 << 16) | 129: return ws_cfg<256, 128, 2, 2>(*dp);
-    case (256 << 16) | 256: return ws_cfg<256, 256, 4, 2>(*dp);
     case (128 << 16) | 96: return ws_cfg<128, 96, 4, 1>(*dp);
     case (128 << 16) | 64: return ws_cfg<128, 64, 2, 2>(*dp);
     case (128 << 16) | 32: return ws_cfg<128, 32, 4, 1>(*dp);

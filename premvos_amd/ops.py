@@ -326,6 +326,8 @@ def _candidates(d: ConvDesc):
         tiles = [(128, 128), (64, 128), (128, 64), (64, 64)]
         if d.precision == _lib.PREC_F32 and m >= 256 * 512 and os.environ.get("PREMVOS_TILE256", "1") != "0":
             tiles.append((256, 128))           # 8 waves of 64x64 at <= 128 VGPRs: four waves per SIMD, half the B staging per MFMA
+        if d.precision == _lib.PREC_F32 and m >= 256 * 64 and d.cout >= 128 and (d.kh, d.kw) == (1, 1):
+            tiles.append((256, 129))           # four waves of 128x64 (round 5; pointwise layers: tools/retile_pointwise.py)
         if d.precision == _lib.PREC_F32 and 64 < d.cout <= 96:
             tiles.append((128, 96))
     out = []
@@ -353,6 +355,9 @@ def _candidates(d: ConvDesc):
     if pwdma_applicable(d) and d.cout > 64 and os.environ.get("PREMVOS_PWDMA", "1") != "0":
         out.append((6, 0, -1, 0, 0))               # tile_hint 6 = LDS-DMA staged pointwise kernel (csrc/conv_pwdma_f32.hip): same sums
     for bm, bn in tiles:
+        if bn == 129:                              # (the 256x128 tile with four 128x64 waves: plain form only -- no k-slices / tail split)
+            out.append(((bm << 16) | bn, 16, -1, 0, 0))
+            continue
         nt = -(-m // bm) * -(-d.cout // bn)
         stages = [16, 32] if (d.precision != _lib.PREC_F32 or (bm, bn) in ((256, 128), (128, 128), (128, 64), (64, 128))) else [16]
         splits = [-1] + ([2, 4] if (nt < 512 and d.k_pad >= 512) else []) + ([8] if (nt < 128 and d.k_pad >= 2048) else [])

@@ -34,12 +34,16 @@ def test_shipped_table_parses_and_holds_legal_configurations():
         hint = choice[0]
         fams.add(hint if hint < 16 else 0)
         if hint >= 16:
-            assert (hint >> 16, hint & 0xFFFF) in {(256, 128), (128, 128), (128, 96), (128, 64), (128, 32), (64, 128), (64, 64), (64, 32)}
+            assert (hint >> 16, hint & 0xFFFF) in {(256, 128), (256, 129), (128, 128), (128, 96), (128, 64), (128, 32), (64, 128), (64, 64), (64, 32)}
             assert choice[1] in (16, 32)
+            if hint & 0xFFFF == 129:                                         # (256 x 128 with four 128 x 64 waves: plain form, pointwise layers)
+                assert tuple(choice[1:]) == (16, -1, 0, 0) and (d.kh, d.kw) == (1, 1) and d.cout >= 128
         ops.numerics_key(d, tuple(choice))                                   # defined for every entry
         if hint == 5:                                                        # an order-neutral stand-in for the implicit GEMM
             assert ops.numerics_key(d, tuple(choice)) == (0, None, None) and d.k_pad in (64, 128) and d.cout % 128 == 0
-    assert fams == {0, 1, 2, 3, 4, 5}           # implicit GEMM, direct, F(2x2) slab / slab-free, F(4x4), short-K streaming pointwise
+        if hint == 6:                                                        # ... and so is the LDS-DMA staged pointwise kernel (round 5)
+            assert ops.numerics_key(d, tuple(choice)) == (0, None, None) and (d.kh, d.kw, d.pt, d.pl) == (1, 1, 0, 0) and d.k_pad >= 32
+    assert fams == {0, 1, 2, 3, 4, 5, 6}        # implicit GEMM, direct, F(2x2) slab / slab-free, F(4x4), short-K streaming / LDS-DMA pointwise
 
 
 def test_rule_choice_is_a_function_of_the_signature_only():

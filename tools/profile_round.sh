@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 # (round 3: the conv configurations come from the shipped table premvos_amd/tune_gfx950.json -- tools/make_tune_table.py -- so
 #  there is no per-run tune cache to fill any more; the profiled runs use one pipeline step per bench step: --scaling weak)
 cp premvos_amd/tune_gfx950.json "$OUT/${TAG}_tune_choices.json"
-W="--scaling weak --file-to-file 0"
+W="--scaling weak --file-to-file 0 --supplementary none"
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 for mode in serial concurrent; do
