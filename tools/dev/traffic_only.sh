@@ -5,7 +5,7 @@ set -u
 TAG=${1:-dev}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
-W="--scaling weak --file-to-file 0"
+W="--scaling weak --file-to-file 0 --supplementary none"
 REPO=$PWD
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $W 2>/dev/null | grep '^{' | tail -1 > "$OUT/${TAG}_bench_weak.json"
 STEPS=$(python -c "import json;print(json.load(open('$OUT/${TAG}_bench_weak.json'))['roofline']['launches_per_step'])")

@@ -10,7 +10,7 @@ import json
 import sys
 
 KERNELS = ("conv_igemm_f32_kernel", "wino_gemm_kernel", "wino_output_kernel", "wino_fused_kernel", "wino4_input_kernel",
-           "wino4_gemm_kernel", "wino4_output_kernel", "splitk_reduce_kernel", "conv_smalln_kernel", "conv_smalln_tile_kernel", "conv_stream_f32_kernel")
+           "wino4_gemm_kernel", "wino4_output_kernel", "splitk_reduce_kernel", "conv_smalln_kernel", "conv_smalln_tile_kernel", "conv_stream_f32_kernel", "conv_pwdma_f32_kernel")
 
 
 def total(path, counter):
