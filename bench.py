@@ -318,15 +318,18 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32", calibrate=True):
     reps = 5
     items = pipe.conv_steps()          # (stage, name, fn, flops_per_step)
     samples = [[] for _ in items]
-    for _ in range(reps):
-        evs = []
-        for _, _, fn, _, _, _ in items:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); fn(); b.record()
-            evs.append((a, b))
-        torch.cuda.synchronize()
-        for i, (a, b) in enumerate(evs):
-            samples[i].append(a.elapsed_time(b))
+    with BoxSampler(torch.cuda.current_device()) as leg_smi:      # the clock / power THIS leg ran under (serial replay: not the timed region's)
+        for _ in range(reps):
+            evs = []
+            for _, _, fn, _, _, _ in items:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); fn(); b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            for i, (a, b) in enumerate(evs):
+                samples[i].append(a.elapsed_time(b))
+    leg_box = leg_smi.summary()
+    leg_clk = (leg_box.get("sclk_mhz_mean_of_xcds") or {}).get("mean")
     tot = [sorted(x)[len(x) // 2] for x in samples]          # median per launch: robust to a throttling transient
     # refinement launches run once per group of frames: weight their time by the calls per step
     mult = [pipe.refine_calls_per_step if st == "refine" else 1 for st, _, _, _, _, _ in items]
@@ -413,6 +416,12 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32", calibrate=True):
             # algorithmic = issued there; `winograd_issued_frac`: FLOPs the Winograd layers actually issue / their time (transform
             # kernels included) / peak
             **_family_split(items, tot, mult),
+            # the leg's own clock: the fp32 MFMA peak scales with the shader clock (157.3 TFLOP/s is 256 CUs x 256 FLOP / clk at 2.4 GHz),
+            # and these kernels hold the socket at its 1.4 kW cap -- `frac` above stays priced against the NOMINAL peak
+            "leg_box": {k: leg_box.get(k) for k in ("sclk_mhz_mean_of_xcds", "socket_power_w", "power_limited_share", "error") if leg_box.get(k) is not None},
+            "peak_at_granted_clock": round(PEAK_F32_TFLOPS * leg_clk / 2400.0, 1) if leg_clk else None,
+            "igemm_family_frac_at_granted_clock": (round(_family_split(items, tot, mult)["igemm_family_frac"] * 2400.0 / leg_clk, 4)
+                                                   if leg_clk and _family_split(items, tot, mult)["igemm_family_frac"] else None),
             "launches_per_step": nl, "flops_per_launch": round(flops / nl, 1), "avg_launch_us": round(1e3 * ms / nl, 2),
             "conv_ms_per_step": round(ms, 3), "conv_ms_each_layer_once": round(sum(tot), 3),
             "per_stage_tflops": {k: round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in per_stage.items()}}
