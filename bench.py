@@ -290,6 +290,35 @@ class BoxSampler:
                 "source": "amdsmi_get_gpu_metrics_info on a host thread during the timed region (nominal sclk 2400 MHz, socket cap 1400 W)"}
 
 
+def mfma_sustained_random(seconds: float = 1.5):
+    """Pure v_mfma_f32_32x32x2_f32 on changing pseudo-random operands, back to back for ``seconds`` (after 0.5 s of settling), with the
+    clock / power it ran under: the fp32 MFMA rate THIS box sustains on real data."""
+    from premvos_amd import _lib
+    lib = _lib.load()
+    sink = torch.zeros(4, device="cuda")
+    blocks, iters, st = 1024, 20000, _lib.current_stream()
+    flops = blocks * 4 * iters * 16 * 4096.0
+
+    def burst(n):
+        for _ in range(n):
+            lib.premvos_mfma_f32_calibrate_random(iters, blocks, sink.data_ptr(), st)
+        torch.cuda.synchronize()
+    t_end = time.perf_counter() + 0.5
+    while time.perf_counter() < t_end:
+        burst(4)
+    n = 0
+    with BoxSampler(torch.cuda.current_device()) as smi:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            burst(4)
+            n += 4
+        dt = time.perf_counter() - t0
+    b = smi.summary()
+    return {"tflops": round(n * flops / dt / 1e12, 1), "seconds": round(dt, 2),
+            "sclk_mhz_mean": (b.get("sclk_mhz_mean_of_xcds") or {}).get("mean"), "socket_power_w_mean": (b.get("socket_power_w") or {}).get("mean"),
+            "power_limited_share": b.get("power_limited_share")}
+
+
 def hbm_ceiling():
     """What a float4 copy sustains on THIS GPU (read + write bytes / time; 1 GiB -> 1 GiB, far beyond the 256 MB Infinity Cache)."""
     from premvos_amd import _lib
@@ -358,6 +387,7 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32", calibrate=True):
     # what the fp32 MFMA pipe sustains on THIS GPU with nothing else going on (pure v_mfma_f32_32x32x2_f32 loop)
     from premvos_amd import _lib
     ceiling = hbm_gbs = float("nan")
+    sustained = None
     if calibrate:
         sink = torch.zeros(4, device="cuda")
         lib, blocks, iters = _lib.load(), 1024, 20000
@@ -369,6 +399,7 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32", calibrate=True):
         cb.synchronize()
         ceiling = blocks * 4 * iters * 16 * 4096.0 / (ca.elapsed_time(cb) * 1e-3) / 1e12
         hbm_gbs = hbm_ceiling()
+        sustained = mfma_sustained_random()
     if net_prec != "fp32":
         # the optional bf16-MFMA modes (never the headline): priced against the dense bf16 peak.  bf16x3 issues three MFMAs per
         # product (hi.hi + hi.lo + lo.hi), so its issue fraction is 3x its algorithmic fraction.
@@ -407,6 +438,9 @@ def roofline(pipe, batch, net_prec="fp32", flow_prec="fp32", calibrate=True):
                        "igemm_family_frac, winograd_issued_frac and mfma_issue_frac for that",
             "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": round(alg_bytes / nl), "mfma_ceiling_measured": round(ceiling, 1),
+            # ... and the same MFMA loop on CHANGING random operands, sustained for 1.5 s: the pipe's power follows the switching activity
+            # of its operands; on real data the socket meets its 1.4 kW cap and the clock gives way (the constant-operand loop never does)
+            "mfma_ceiling_sustained_random_data": sustained,
             # the box factor of the memory system (GB/s of a float4 copy, read + write) and ONE canonical layer of the pipeline --
             # Xception middle flow 728 -> 728 pointwise + residual at M = 100 000 pixels (xception.py:508-550), as this run timed it
             "hbm_ceiling_measured": hbm_gbs, **_canonical_layer(items, tot),

@@ -321,6 +321,12 @@ int premvos_refine_output_f32(const float* logits, int32_t logits_ps, int32_t lh
  * (bench.py: roofline.mfma_ceiling_measured). */
 int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void* stream);
 
+/* The same loop on CHANGING pseudo-random operands (eight A and B registers per lane, another pair for every MFMA): the fp32 matrix
+ * pipe's power follows the switching activity of its operands, and on random data the socket meets its cap and the shader clock gives
+ * way (the constant operands above never do).  Timed over >= 1 s: the fp32 MFMA rate a box sustains on real data
+ * (bench.py: roofline.mfma_ceiling_sustained_random_data). */
+int premvos_mfma_f32_calibrate_random(int64_t iters, int32_t blocks, float* sink, void* stream);
+
 /* Calibration kernel: copies n_float4 16-byte words src -> dst (one word per thread, flat grid);
  * 2 * 16 * n_float4 bytes / time = the streaming HBM rate the GPU sustains (bench.py: roofline.hbm_ceiling_measured).  Use
  * buffers well beyond the 256 MB Infinity Cache. */

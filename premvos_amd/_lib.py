@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 15         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
+ABI_VERSION = 16         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ACT_SPLIT8_BF16 = 0x200      # premvos_dwconv3x3_f32: store the resident S8 layout ({hi8, lo8} per group of 8 channels) for premvos_conv_bf16x3_s8_f32
@@ -72,6 +72,7 @@ SIGNATURES = {
     "premvos_broadcast_pixel_f32": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "premvos_refine_output_f32": [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "premvos_mfma_f32_calibrate": [C.c_int64, _i32, _vp, _vp],
+    "premvos_mfma_f32_calibrate_random": [C.c_int64, _i32, _vp, _vp],
     "premvos_hbm_copy_calibrate": [_vp, _vp, C.c_int64, _vp],
     "premvos_digest_u64": [_vp, C.c_int64, _i32, _i32, _vp, _vp],
     "premvos_conv_wino4_slab_f32": [C.POINTER(ConvDesc), _vp, C.c_int64, _i32, _i32, _i32, _vp],

@@ -1091,6 +1091,46 @@ __global__ __launch_bounds__(256) void mfma_f32_calibrate_kernel(long iters, flo
 }
 }  // namespace
 
+namespace {
+// The same loop on CHANGING operands (round 5): eight pseudo-random A and B registers per lane, a different pair for every MFMA.  The
+// fp32 matrix pipe's power depends on the switching activity of its operands (profiles/r05_power_data.txt: the implicit GEMM draws
+// 0.83 kW on all-zero operands and 1.35 ... 1.40 kW -- the socket cap -- on random ones, where the shader clock gives way by 3 ... 5 %);
+// the constant operands of the kernel above never meet the cap.  Timed over a second or more this is the fp32 MFMA rate a box
+// sustains ON REAL DATA -- the ceiling a GEMM's loop can be priced against beside the nominal 157.3.
+__global__ __launch_bounds__(256) void mfma_f32_calibrate_random_kernel(long iters, float* sink) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a[8], b[8];
+  unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                 // values in (-1, 1) with full mantissas, ~N(0, 0.33)-like spread
+    h = h * 1664525u + 1013904223u; a[j] = ((int)(h >> 8) - (1 << 23)) * (1.0f / (1 << 23));
+    h = h * 1664525u + 1013904223u; b[j] = ((int)(h >> 8) - (1 << 23)) * (1.0f / (1 << 23));
+  }
+  for (long it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(4 * u + i) & 7], b[(4 * u + i + u) & 7], acc[i], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[i][r];
+  if (t == 123.456f) sink[0] = t;
+}
+}  // namespace
+
+extern "C" int premvos_mfma_f32_calibrate_random(int64_t iters, int32_t blocks, float* sink, void* stream) {
+  PV_REQUIRE(iters > 0 && blocks > 0 && sink != nullptr, "mfma_calibrate_random: bad arguments");
+  hipLaunchKernelGGL(mfma_f32_calibrate_random_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), (long)iters, sink);
+  return premvos::check_launch("mfma_f32_calibrate_random");
+}
+
 extern "C" int premvos_mfma_f32_calibrate(int64_t iters, int32_t blocks, float* sink, void* stream) {
   PV_REQUIRE(iters > 0 && blocks > 0 && sink != nullptr, "mfma_calibrate: bad arguments");
   hipLaunchKernelGGL(mfma_f32_calibrate_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), (long)iters,
@@ -1144,4 +1184,4 @@ extern "C" int premvos_digest_u64(const void* buf, int64_t pixels, int32_t c, in
   return premvos::check_launch("digest");
 }
 
-extern "C" int premvos_abi_version(void) { return 15; }   // bump with every change of include/premvos_hip.h
+extern "C" int premvos_abi_version(void) { return 16; }   // bump with every change of include/premvos_hip.h

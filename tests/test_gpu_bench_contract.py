@@ -43,6 +43,8 @@ def test_bench_line_through_the_distributed_path():
     # the line carries its own box factors: HBM copy rate, one canonical layer, clock / power over the timed region
     assert 2000 < r["hbm_ceiling_measured"] < 8000 and r["canonical_layer"]["us"] > 0 and "728 -> 728" in r["canonical_layer"]["what"]
     assert "error" in d["box"] or (d["box"]["samples"] >= 1 and 500 < d["box"]["sclk_mhz_mean_of_xcds"]["mean"] < 3000)
+    sr = r["mfma_ceiling_sustained_random_data"]              # the pure MFMA loop on changing random operands, sustained: <= the burst on constants
+    assert 100 < sr["tflops"] <= r["mfma_ceiling_measured"] * 1.01 and sr["seconds"] >= 1.0
     # the roofline leg's own clock sample and the peak / family fraction at that clock (`frac` itself stays priced at the nominal peak)
     assert "error" in r["leg_box"] or (r["peak_at_granted_clock"] <= 157.3 * 1.02 and
                                        abs(r["igemm_family_frac_at_granted_clock"] * r["peak_at_granted_clock"] - r["igemm_family_frac"] * 157.3) < 0.5)

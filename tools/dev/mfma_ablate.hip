@@ -320,11 +320,40 @@ void run4(int blocks, long stages, const float* g, float* sink) {
          lds_bytes, fl / (ms * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
 }
 
+template <int V>
+double spin(int blocks, long stages, const float* g, float* sink, int lds, double secs) {      // launches k<V> back to back for `secs`; TFLOP/s
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  k<V><<<blocks, 256, lds>>>(stages, g, sink); hipDeviceSynchronize();
+  long n = 0; float ms = 0.f;
+  hipEventRecord(a);
+  do {
+    for (int i = 0; i < 20; ++i) k<V><<<blocks, 256, lds>>>(stages, g, sink);
+    n += 20;
+    hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+  } while (ms < secs * 1e3);
+  return (double)n * blocks * 4 * stages * 32 * 4096.0 / (ms * 1e-3) / 1e12;
+}
+
 int main(int argc, char** argv) {
   float *g, *sink;
   hipMalloc(&g, (1L << 25) * 4); hipMemset(g, 0, (1L << 25) * 4); hipMalloc(&sink, 64);
   const long stages = 4000;
   const int lds = 2 * (BM + BN) * RS * 4;           // 40960 B -> 3-4 workgroups per CU
+  if (argc >= 4 && argv[1][0] == 'p') {             // power ladder (tools/dev/power_ladder.py): `power <variant> <seconds>`
+    const int v = atoi(argv[2]); const double secs = atof(argv[3]);
+    double tf = 0;
+    switch (v) {
+      case 0: tf = spin<0>(768, stages, g, sink, lds, secs); break;
+      case 1: tf = spin<1>(768, stages, g, sink, lds, secs); break;
+      case 2: tf = spin<2>(768, stages, g, sink, lds, secs); break;
+      case 3: tf = spin<3>(768, stages, g, sink, lds, secs); break;
+      case 4: tf = spin<4>(768, stages, g, sink, lds, secs); break;
+      case 5: tf = spin<5>(768, stages, g, sink, lds, secs); break;
+      default: tf = spin<6>(768, stages, g, sink, lds, secs); break;
+    }
+    printf("variant %d: %.1f TFLOP/s\n", v, tf);
+    return 0;
+  }
   printf("WMAP %d\n", WMAP);
   run4<2, 2>(512, stages, g, sink); run4<2, 2>(768, stages, g, sink); run4<4, 2>(256, stages, g, sink); run4<4, 2>(512, stages, g, sink);
   run2<2, 2>(512, stages, g, sink);
