@@ -244,3 +244,46 @@ def test_rpn_proposals_kernel_fuzz_with_exact_ties_and_duplicate_boxes(seed, fh,
     assert n == len(pidx), (n, len(pidx))
     assert np.array_equal(oi[0, :n].cpu().numpy(), pidx.astype(np.int32))
     assert np.array_equal(osc[0, :n].cpu().numpy(), ps)
+
+
+def test_roi_align_row_kernel_equals_the_per_bin_kernel_on_adversarial_boxes(tmp_path):
+    """Round 5: `premvos_roi_align_f32` runs the row-walking kernel (a thread keeps the corner pixels of its four feature-map rows in
+    registers); PREMVOS_ROI_ALIGN=bin selects the per-bin kernel it replaced.  Same bits on boxes that leave the map on every side,
+    degenerate (zero / negative extent), sub-pixel, integer-aligned (floor == ceil) and frame-sized boxes, ragged counts."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "roi.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})\n"
+        "from premvos_amd import _lib, ops\n"
+        "lib = _lib.load(); torch.manual_seed(3)\n"
+        "B, R, fh, fw, C = 3, 24, 23, 37, 72\n"
+        "fm = ops.NHWC(torch.randn((B, fh, fw, C), device='cuda'), c=C)\n"
+        "W, H = fw * 16.0, fh * 16.0\n"
+        "rng = np.random.default_rng(11)\n"
+        "special = [[-50, -40, 80, 90], [W - 60, H - 30, W + 100, H + 70], [-200, -200, W + 200, H + 200], [100, 100, 100, 100], [120, 90, 110, 80],\n"
+        "           [0, 0, W - 16, H - 16], [16, 32, 16 + 28 * 16, 32 + 28 * 16], [50.3, 60.7, 50.9, 61.2], [0, 0, 448, 448], [W - 1, H - 1, W, H],\n"
+        "           [-1000, 10, -900, 60], [10, H + 500, 90, H + 600]]\n"
+        "rois = np.zeros((B, R, 4), np.float32)\n"
+        "for b in range(B):\n"
+        "    for r in range(R):\n"
+        "        if r < len(special): rois[b, r] = special[(r + b) % len(special)]\n"
+        "        else:\n"
+        "            wh = rng.uniform(4, 400, 2); xy = rng.uniform(-50, [W, H]); rois[b, r] = [xy[0], xy[1], xy[0] + wh[0], xy[1] + wh[1]]\n"
+        "rt = torch.from_numpy(rois).cuda()\n"
+        "cnt = torch.tensor([R, 7, 0], dtype=torch.int32, device='cuda')\n"
+        "out = ops.NHWC(torch.full((B * R, 14, 14, C), -3.0, device='cuda'), c=C)\n"
+        "_lib.check(lib.premvos_roi_align_f32(fm.ptr, fm.ps, B, fh, fw, C, rt.data_ptr(), cnt.data_ptr(), R, 1.0 / 16, 14, out.ptr, out.ps, _lib.current_stream()), 'roi')\n"
+        "torch.cuda.synchronize()\n"
+        "np.save(sys.argv[1], out.buf.cpu().numpy())\n")
+    outs = []
+    for mode in ("bin", "row"):
+        f = tmp_path / f"{mode}.npy"
+        r = subprocess.run([sys.executable, str(script), str(f)], env=dict(os.environ, PREMVOS_ROI_ALIGN=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    assert np.isfinite(outs[0]).all() and not (outs[0] == -3.0).any()                 # every slot written (invalid RoIs: zeros)
+    assert np.array_equal(outs[0].view(np.int32), outs[1].view(np.int32))             # bit patterns
+    assert float(np.abs(outs[0][24 + 7:48]).max()) == 0.0 and float(np.abs(outs[0][48:]).max()) == 0.0    # beyond an image's count: zeros
