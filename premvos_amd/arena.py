@@ -76,8 +76,8 @@ class Arena:
         if not (self.on and pooled):
             t = torch.empty(shape, dtype=torch.float32, device="meta") if self.dry else \
                 torch.zeros(shape, dtype=torch.float32, device=self.device)
-            if not self.dry:
-                self.loose.append(t)
+            self.loose.append(t)                 # (pass 1: keeps id() unique; a loose tensor may be released -- nothing to record)
+            self._ids[id(t)] = -1
             return t
         nbytes = 4 * n * h * w * ps
         self.tick += 1
@@ -93,14 +93,30 @@ class Arena:
         self.cursor += 1
         return self.bufs[kind][o:o + n * h * w * ps].view(n, h, w, ps)
 
-    def release(self, t: torch.Tensor) -> None:
-        """The last launch reading ``t`` has been appended: its bytes may be handed to tensors allocated from now on."""
+    def side(self, shape, dtype) -> torch.Tensor:
+        """A zero-filled tensor of the plan that is NOT activation memory (frames, boxes, counters, result blocks, scratch): shape-only
+        in pass 1 -- the dry pass used to allocate (and drop) every one of them for real, > 1 GB for a 160-crop plan at 1080p --
+        and a tensor of its own in pass 2."""
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        return torch.empty(shape, dtype=dtype, device="meta") if self.dry else torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def release(self, t) -> None:
+        """The last launch reading ``t`` has been appended: its bytes may be handed to tensors allocated from now on.
+        ``t`` is what ``alloc`` returned (or the ``ops.NHWC`` wrapped around exactly that tensor: full channel range, all images).
+        A channel window (``NHWC.slice``) or an image range (``NHWC.images``) shares its parent's storage -- releasing one would end
+        the lifetime of the whole buffer while its other readers are still in the list -- and an unknown tensor would be ignored
+        silently: both are errors."""
+        buf = getattr(t, "buf", t)
+        if buf is not t and (t.coff != 0 or t.ps - t.c >= 4):
+            raise ValueError("Arena.release: a channel window of a tensor, not the tensor alloc() returned")
         if not self.on:
             return
         self.tick += 1
         if self.dry:
-            i = self._ids.get(id(t))
-            if i is not None and self.items[i][2] is None:
+            i = self._ids.get(id(buf))
+            if i is None:
+                raise ValueError("Arena.release: not a tensor of this arena (an image range / view, or released twice through a copy)")
+            if i >= 0 and self.items[i][2] is None:
                 self.items[i][2] = self.tick
 
     # -- between the passes ------------------------------------------------------------------------------------------

@@ -499,7 +499,10 @@ def _entry_for(d: ConvDesc):
     Winograd candidates withheld -- instead of failing in the library's argument check at launch time."""
     cand = _TUNE_CACHE[_sig(d)]
     hint = cand[0]
-    if (hint == 5 and not stream_applicable(d)) or (hint == 6 and not pwdma_applicable(d)):
+    # (PREMVOS_PWDMA=0 is the documented A/B switch of the LDS-DMA pointwise kernel: it must also silence the shipped table's
+    #  hint-6 entries, not only the candidate list -- same sums either way)
+    if (hint == 5 and not stream_applicable(d)) or \
+            (hint == 6 and (not pwdma_applicable(d) or os.environ.get("PREMVOS_PWDMA", "1") == "0")):
         return ((128 << 16) | 128, 16, -1, 0, 0)
     if hint in (2, 3, 4) and cand not in _candidates(d):
         w2, w4, d.wgt_wino, d.wgt_wino4 = d.wgt_wino, d.wgt_wino4, None, None

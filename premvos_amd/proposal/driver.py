@@ -163,14 +163,14 @@ def fill_full_mask(box, mask, shape) -> np.ndarray:
 
 
 def clip_boxes(boxes: np.ndarray, shape) -> np.ndarray:
-    """common.py:107-119."""
-    orig_shape = boxes.shape
-    boxes = boxes.reshape([-1, 4])
-    h, w = shape
-    boxes[:, [0, 1]] = np.maximum(boxes[:, [0, 1]], 0)
-    boxes[:, 2] = np.minimum(boxes[:, 2], w)
-    boxes[:, 3] = np.minimum(boxes[:, 3], h)
-    return boxes.reshape(orig_shape)
+    """Boxes (x0, y0, x1, y1 in the last axis) limited to an image of ``shape`` = (height, width): the top-left corner to
+    >= 0, x1 to <= width, y1 to <= height -- one-sided, as the reference does it (common.py:107-119 leaves x0 / y0 above the
+    frame and negative x1 / y1 alone).  Works in place on a C-contiguous input (eval.py:94 relies on that) and returns it."""
+    flat = boxes.reshape(-1, 4)                 # a view for contiguous input: the clamps below write through to ``boxes``
+    corner, far = flat[:, :2], flat[:, 2:]
+    np.maximum(corner, 0, out=corner)
+    np.minimum(far, np.asarray((shape[1], shape[0]), dtype=flat.dtype), out=far)
+    return flat.reshape(boxes.shape)
 
 
 def _to_results(boxes, probs, labels, posteriors, second_labels, second_posteriors, scale, orig_shape, masks=None):

@@ -93,7 +93,7 @@ class _Plan:
         def release(*vs):              # the last launch that reads these tensors has been appended
             for v in vs:
                 if v is not None:
-                    A.release(v.buf)
+                    A.release(v)
 
         def conv(x, name, out, uid=None, out_s8=None, res_s8=None, **kw):
             """``x`` in the resident split layout S8 (bf16x3 mode) -> csrc/conv_bf16x3_s8.hip (fp32 ``out`` and / or S8 ``out_s8``;
@@ -199,10 +199,10 @@ class _Plan:
         conv(hid, "rpn/heads", self.rpn_out)
         release(hid)
         R = TEST_POST_NMS_TOPK
-        self.rois = torch.zeros((b, R, 4), dtype=torch.float32, device=dev)
-        self.roi_scores = torch.zeros((b, R), dtype=torch.float32, device=dev)
-        self.roi_idx = torch.zeros((b, R), dtype=torch.int32, device=dev)
-        self.roi_count = torch.zeros((b,), dtype=torch.int32, device=dev)
+        self.rois = A.side((b, R, 4), torch.float32)
+        self.roi_scores = A.side((b, R), torch.float32)
+        self.roi_idx = A.side((b, R), torch.int32)
+        self.roi_count = A.side((b,), torch.int32)
         ca = net.cell_anchors_dev
 
         def rpn(o=self.rpn_out):
@@ -233,10 +233,10 @@ class _Plan:
         self.head = alloc(b * R, 1, 1, nh)
         conv(gp, "heads", self.head)
         M = RESULTS_PER_IM
-        self.final_boxes = torch.zeros((b, M, 4), dtype=torch.float32, device=dev)
-        self.final_probs = torch.zeros((b, M), dtype=torch.float32, device=dev)
-        self.final_idx = torch.zeros((b, M), dtype=torch.int32, device=dev)
-        self.final_count = torch.zeros((b,), dtype=torch.int32, device=dev)
+        self.final_boxes = A.side((b, M, 4), torch.float32)
+        self.final_probs = A.side((b, M), torch.float32)
+        self.final_idx = A.side((b, M), torch.int32)
+        self.final_count = A.side((b,), torch.int32)
 
         def tail(hd=self.head):
             _lib.check(lib.premvos_frcnn_tail_f32(

@@ -109,7 +109,7 @@ class _Plan:
 
         def release(v: Optional[NHWC]):                         # the last launch that reads ``v`` has been appended
             if v is not None:
-                A.release(v.buf)
+                A.release(v)
 
         # bf16x3 mode (round 4): the depthwise half of a separable conv stores its result in the resident split layout S8 (in place of
         # the floats: {hi8, lo8} per group of 8 channels) and the pointwise half runs on csrc/conv_bf16x3_s8.hip, which stages it by
@@ -159,11 +159,11 @@ class _Plan:
             return alloc_s8(n, h, w, c) if split_pw and (name is None or name in S8) else alloc(n, h, w, c)   # pointwise half runs on the S8 kernel
 
         S = INPUT_SIZE
-        self.frames = torch.zeros((G, H, W, 3), dtype=torch.uint8, device=dev)
+        self.frames = A.side((G, H, W, 3), torch.uint8)
         NG = 1 if packed else G        # leading dimension of the per-frame result views ([1, slots, ...] when packed)
-        self.boxes_g = torch.zeros((NG, PF, 4), dtype=torch.float32, device=dev)      # y0 x0 y1 x1
-        self.count = torch.zeros((G,), dtype=torch.int32, device=dev)
-        self.crops = torch.zeros((NG, PF, 4), dtype=torch.int32, device=dev)
+        self.boxes_g = A.side((NG, PF, 4), torch.float32)      # y0 x0 y1 x1
+        self.count = A.side((G,), torch.int32)
+        self.crops = A.side((NG, PF, 4), torch.int32)
         self.frame, self.boxes = self.frames[0], self.boxes_g[0]                      # single-frame views
         self.net_in = alloc(P, S, S, 4)
 
@@ -294,13 +294,13 @@ class _Plan:
         conv(d, "logits/features", self.logits)
 
         # SegmentationSoftmax eval branch + conf_score
-        self.mask_g = torch.zeros((NG, PF, H, W), dtype=torch.uint8, device=dev)
-        self.posterior_g = torch.zeros((NG, PF, H, W), dtype=torch.float32, device=dev) if with_posterior else None
-        self.conf_g = torch.zeros((NG, PF), dtype=torch.float32, device=dev)
+        self.mask_g = A.side((NG, PF, H, W), torch.uint8)
+        self.posterior_g = A.side((NG, PF, H, W), torch.float32) if with_posterior else None
+        self.conf_g = A.side((NG, PF), torch.float32)
         self.mask, self.conf = self.mask_g[0], self.conf_g[0]                         # single-frame views
         self.posterior = self.posterior_g[0] if with_posterior else None
         wsb = int(lib.premvos_refine_output_workspace_bytes(PF, S, H, W))
-        self.ws = torch.zeros((wsb + 15) // 16 * 4, dtype=torch.float32, device=dev)
+        self.ws = A.side((wsb + 15) // 16 * 4, torch.float32)
 
         def out_layer(lg=self.logits):
             if packed:

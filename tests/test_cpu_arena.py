@@ -106,3 +106,39 @@ def test_plans_of_one_lane_share_their_bytes():
     a16 = arena.two_pass("cpu", b16, shared=lane)               # a larger one replaces the lane's buffer; the earlier plans keep theirs
     assert lane["f32"] is a16.bufs["f32"] and a16.bufs["f32"] is not big and a8.bufs["f32"] is big
     assert a16.bufs["f32"].numel() * 4 >= a16.report()["peak_live_bytes"]
+
+
+def test_release_refuses_channel_windows_views_and_unknown_tensors():
+    """``NHWC.slice`` shares its parent's storage, so releasing a window would end the whole buffer's lifetime; an
+    image range is a different tensor object and used to be ignored silently."""
+    from premvos_amd.ops import NHWC
+
+    def build(A):
+        cat = NHWC(A.alloc(2, 4, 4, 32))
+        A.release(cat.slice(0, 32))                            # the full range of the buffer: the same thing as the tensor itself
+
+    arena.two_pass("cpu", build)
+    for bad in ("window", "offset-window", "images", "foreign", "s8-window"):
+        def build(A, bad=bad):
+            cat = NHWC(A.alloc(2, 4, 4, 32))
+            s8 = NHWC(A.alloc(2, 4, 4, 32, "s8"), layout="s8")
+            A.release({"window": lambda: cat.slice(0, 16), "offset-window": lambda: cat.slice(16, 16),
+                       "images": lambda: cat.images(0, 1), "foreign": lambda: torch.zeros(1, 1, 1, 4),
+                       "s8-window": lambda: s8.slice(8, 8)}[bad]())
+        with pytest.raises(ValueError):
+            arena.two_pass("cpu", build)
+
+
+def test_side_tensors_take_no_memory_in_the_dry_pass():
+    kinds = []
+
+    def build(A):
+        t = A.side((3, 5), torch.int32)
+        kinds.append((A.dry, t.device.type, tuple(t.shape), t.dtype))
+        u = A.side(7, torch.float32)
+        assert tuple(u.shape) == (7,)
+        if not A.dry:
+            assert int(t.abs().sum()) == 0
+
+    arena.two_pass("cpu", build)
+    assert kinds == [(True, "meta", (3, 5), torch.int32), (False, "cpu", (3, 5), torch.int32)]

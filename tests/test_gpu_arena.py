@@ -67,3 +67,57 @@ def test_refinement_plan_on_the_arena_is_bit_identical(monkeypatch, precision):
             assert rep_["arena_bytes"] <= 1.25 * rep_["peak_live_bytes"], rep_
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_plans_of_one_lane_interleaved_on_shared_bytes_keep_their_bits(monkeypatch, precision):
+    """the refinement plans of one lane live in ONE shared buffer that is never re-zeroed.  Plan A, plan B (another slot
+    count: other offsets for every tensor), plan A again -- through replayed graphs and the packed eager form -- with the arena
+    poisoned (NaN bit patterns) before every run: the masks / conf / posterior bits are the ones of PREMVOS_ARENA=0, i.e. no
+    kernel reads a byte that the SAME run has not written (crop slots at or beyond ``count`` and unused packed slots included)."""
+    from premvos_amd.refinement import RefinementNet
+    nm = 2
+    w = R.synth_weights(1, nm)
+    rng = np.random.default_rng(2)
+    frames = torch.from_numpy(rng.integers(0, 256, (2, 120, 200, 3), dtype=np.uint8)).cuda()
+    b3 = torch.tensor([BOXES, BOXES[::-1]]).cuda()                     # plan A: 2 frames x 3 boxes
+    b5 = torch.tensor([BOXES + BOXES[:2], (BOXES + BOXES[:2])[::-1]]).cuda()   # plan B: 2 frames x 5 boxes
+    cnt = torch.tensor([2, 3], dtype=torch.int32).cuda()              # frame 0 leaves a slot beyond its count
+
+    def sequence(net, poison):
+        out = []
+
+        def fill():
+            if poison:
+                torch.cuda.synchronize()
+                for kinds in net._lane_bytes.values():
+                    for buf in kinds.values():
+                        buf.view(torch.int32).fill_(0x7FC00001)      # a quiet NaN as fp32; {NaN, tiny} as a bf16 pair
+        for step in ("A", "B", "A", "packed", "B", "packed-small", "A"):
+            fill()
+            if step == "A":
+                p = net.refine_group(frames, b3, counts=cnt, with_posterior=True)
+                for t in (p.mask_g, p.conf_g, p.posterior_g):          # (the valid slots: what a caller may read)
+                    out += [t[0, :2].clone(), t[1, :3].clone()]
+            elif step == "B":
+                p = net.refine_group(frames, b5, with_posterior=True)
+                out += [p.mask_g.clone(), p.conf_g.clone(), p.posterior_g.clone()]
+            elif step == "packed":
+                q = net.refine_packed(frames, [b3[0, :2], b5[1]], slots=8, max_frames=2)
+                out += [q.mask_g[0, :7].clone(), q.conf_g[0, :7].clone()]
+            else:
+                q = net.refine_packed(frames[:1], [b3[0, :1]], slots=2, max_frames=2)
+                out += [q.mask_g[0, :1].clone(), q.conf_g[0, :1].clone()]
+            torch.cuda.synchronize()
+        return out
+
+    monkeypatch.setenv("PREMVOS_ARENA", "0")
+    ref = sequence(RefinementNet(w, nm, use_graph=True, precision=precision), poison=False)
+    monkeypatch.setenv("PREMVOS_ARENA", "1")
+    net = RefinementNet(w, nm, use_graph=True, precision=precision)
+    got = sequence(net, poison=True)
+    assert len(net._lane_bytes[0]) >= 1 and len({id(p.arena.bufs["f32"]) for p in net._plans.values()}) <= 2   # the plans do share
+    for i, (a, b) in enumerate(zip(ref, got)):
+        if a.dtype.is_floating_point:
+            assert not torch.isnan(b).any(), i
+        assert torch.equal(a, b), i
