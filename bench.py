@@ -211,7 +211,7 @@ def file_to_file(n_frames: int, chunk: int):
         assert n == n_frames
         props = sum(len(json.load(open(os.path.join(out, "combined_proposals", "clip", f"{i:05d}.json")))) for i in range(n_frames))
         files = sum(len(fs) for _, _, fs in os.walk(out))
-        return {"streaming_driver_fps": round(n_frames / min(times[1:]), 2), "cold_run_s": round(times[0], 1),
+        res = {"streaming_driver_fps": round(n_frames / min(times[1:]), 2), "cold_run_s": round(times[0], 1),
                 "warm_runs_s": [round(t, 2) for t in times[1:]], "frames": n_frames, "chunk": chunk,
                 "proposals_per_frame": round(props / n_frames, 1), "files_written": files, "n_gpus": 1, "measured_by_this_run": True,
                 "cold_start_overhead_s": round(times[0] - min(times[1:]), 2),          # plans, buffers, first launches: cold minus warm
@@ -219,6 +219,22 @@ def file_to_file(n_frames: int, chunk: int):
                 "hbm_process_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),                # ... on top of the bench's pipeline object
                 "what": "python -m premvos_amd.stream's pipeline object on a synthetic 480x854 JPEG sequence (quality 95): decode -> flow + "
                         "proposals x2 + combine + refinement -> .flo / JSON / COCO-RLE files; `value` above stays the HBM-resident metric"}
+        ingest = None
+        if os.environ.get("PREMVOS_BENCH_MERGE_INGEST", "1") != "0":
+            # the merge rank of an 8-rank gathered job on THIS GPU (tools/time_merge_ingest.py): the same pipeline object computes rank
+            # 0's share while the recorded buffers of 7 other ranks arrive with every round; >= 430 frames/s = 8 x the file-to-file rate
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("time_merge_ingest", os.path.join(ROOT, "tools", "time_merge_ingest.py"))
+                tmi = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(tmi)
+                job = tmi.build_job(os.path.join(root, "ingest"), 64, 8, weights=False)
+                ingest = tmi.measure(sp, job["clips"], 64, 8, modes=("beside",), reference=False)
+                ingest["measured_by_this_run"] = True
+            except Exception as e:           # noqa: BLE001 -- a secondary leg must not take the contract line down
+                ingest = {"error": f"{type(e).__name__}: {e}"[:300], "measured_by_this_run": False}
+            sp.out = out
+        return res, ingest
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -790,7 +806,9 @@ def main():
         # driver -- by THIS run at N = 1, after the timed region; `value` above is the HBM-resident metric, never this
         if world == 1 and a.frame == "480p" and a.file_to_file > 0 and prec == "fp32":
             try:
-                out["file_to_file"] = file_to_file(a.file_to_file, int(os.environ.get("PREMVOS_STREAM_BATCH", "8")))
+                out["file_to_file"], ingest = file_to_file(a.file_to_file, int(os.environ.get("PREMVOS_STREAM_BATCH", "8")))
+                if ingest is not None:
+                    out["merge_ingest"] = ingest
             except Exception as e:           # noqa: BLE001 -- a secondary leg must not take the contract line down
                 out["file_to_file"] = {"error": f"{type(e).__name__}: {e}"[:300], "measured_by_this_run": False}
         # supplementary modes under the same run's clock (never `value`): the fp32 object is freed first

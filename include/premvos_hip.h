@@ -409,6 +409,16 @@ int premvos_mask_overlap_u8(const uint8_t* a, int32_t na, const uint8_t* b, int3
 int64_t premvos_rle_workspace_bytes(int32_t n, int32_t h, int32_t w);
 int premvos_rle_boundaries_u8(const uint8_t* masks, int32_t n, int32_t h, int32_t w, int32_t* positions,
                               int32_t capacity, int32_t* nruns, void* workspace, void* stream);
+/* The same boundaries for the n masks of a CHUNK of frames, POOLED: mask i's ascending positions go to
+ * pool[offsets[i] .. offsets[i+1]) with offsets[0] = 0 -- one variable-length stream instead of n fixed-capacity rows, so that a
+ * rank can hand the merge rank run lengths instead of masks (the RLE strings FewShotSegmentationForwarder.py:140-142 builds per
+ * box are then pure host work on a few integers per run).  Mask i = the h x w top-left window of masks + i*mask_stride with
+ * row_stride bytes between rows (masks inside a larger staging block).  offsets[n] = the total number of boundaries; it may exceed
+ * pool_capacity: then only the entries below pool_capacity were stored and the caller falls back to the masks themselves.
+ * workspace: premvos_rle_workspace_bytes(n, h, w). */
+int premvos_rle_boundaries_pooled_u8(const uint8_t* masks, int32_t n, int32_t h, int32_t w, int64_t mask_stride,
+                                     int32_t row_stride, int32_t* pool, int32_t pool_capacity, int32_t* offsets,
+                                     void* workspace, void* stream);
 
 /* Masks on the wire (ONE gather of fixed-size buffers per chunk to the merge rank, masks bit-packed): n mask
  * bytes (nonzero = foreground) -> ceil(n/8) bytes, bit k of byte i = masks[8i + k] != 0; and back to {0,1} bytes.  Replaces the
@@ -421,6 +431,11 @@ int premvos_mask_unpack_bits_u8(const uint8_t* bits, int64_t n, uint8_t* masks, 
  * length or -1 -- the "counts" string of every mask the refinement / merge stages write
  * (forwarding/FewShotSegmentationForwarder.py:141-142). */
 int64_t premvos_rle_counts_to_string_host(const int64_t* counts, int64_t n, char* out, int64_t cap);
+/* Host-side utility (no GPU work): the "counts" strings of n masks from their pooled boundaries (host copies of `pool` /
+ * `offsets` above; hw = h*w), written back to back into `out`; string i = out[str_offsets[i] .. str_offsets[i+1]).  Returns the
+ * total length or -1 when `cap` is too small (13 bytes per run always suffice). */
+int64_t premvos_rle_strings_host(const int32_t* pool, const int32_t* offsets, int32_t n, int64_t hw, char* out, int64_t cap,
+                                 int64_t* str_offsets);
 
 #ifdef __cplusplus
 }

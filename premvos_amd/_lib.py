@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 16         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
+ABI_VERSION = 17         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ACT_SPLIT8_BF16 = 0x200      # premvos_dwconv3x3_f32: store the resident S8 layout ({hi8, lo8} per group of 8 channels) for premvos_conv_bf16x3_s8_f32
@@ -85,6 +85,7 @@ SIGNATURES = {
     "premvos_mask_pack_bits_u8": [_vp, C.c_int64, _vp, _vp],
     "premvos_mask_unpack_bits_u8": [_vp, C.c_int64, _vp, _vp],
     "premvos_rle_boundaries_u8": [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
+    "premvos_rle_boundaries_pooled_u8": [_vp, _i32, _i32, _i32, C.c_int64, _i32, _vp, _i32, _vp, _vp, _vp],
     "premvos_frcnn_tail_f32": [_vp, _i32, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32,
                                _f32, _vp, _vp, _vp, _vp, _vp],
 }
@@ -142,6 +143,8 @@ def load():
     lib.premvos_refine_output_workspace_bytes.restype = C.c_int64
     lib.premvos_rle_counts_to_string_host.argtypes = [_vp, C.c_int64, _vp, C.c_int64]
     lib.premvos_rle_counts_to_string_host.restype = C.c_int64
+    lib.premvos_rle_strings_host.argtypes = [_vp, _vp, _i32, C.c_int64, _vp, C.c_int64, _vp]
+    lib.premvos_rle_strings_host.restype = C.c_int64
     lib.premvos_rle_workspace_bytes.argtypes = [_i32, _i32, _i32]
     lib.premvos_rle_workspace_bytes.restype = C.c_int64
     lib.premvos_jpeg_workspace_bytes.argtypes = [_vp]

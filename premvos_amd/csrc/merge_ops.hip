@@ -83,21 +83,21 @@ __global__ __launch_bounds__(256) void mask_overlap_kernel(const uint8_t* __rest
 // Pass 1 counts boundaries per chunk of RLE_CHUNK positions, pass 2 writes them in ascending order.
 constexpr int RLE_CHUNK = 2048;   // 8 positions per thread
 
-__device__ inline int rle_val(const uint8_t* m, int h, int w, long q) {
+__device__ inline int rle_val(const uint8_t* m, int h, int rs, long q) {       // rs: bytes between rows (>= the mask's width)
   const int x = (int)(q / h), y = (int)(q - (long)x * h);
-  return m[(long)y * w + x] != 0;
+  return m[(long)y * rs + x] != 0;
 }
 
-__global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restrict__ masks, int h, int w, int nchunks,
+__global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restrict__ masks, int h, int w, long ms, int rs, int nchunks,
                                                         int* __restrict__ chunk_counts) {
   const long hw = (long)h * w;
-  const uint8_t* m = masks + (long)blockIdx.y * hw;
+  const uint8_t* m = masks + (long)blockIdx.y * ms;
   const long q0 = (long)blockIdx.x * RLE_CHUNK + (long)threadIdx.x * 8;
   int c = 0;
   if (q0 < hw) {
-    int prev = q0 == 0 ? 0 : rle_val(m, h, w, q0 - 1);
+    int prev = q0 == 0 ? 0 : rle_val(m, h, rs, q0 - 1);
     for (int k = 0; k < 8 && q0 + k < hw; ++k) {
-      const int v = rle_val(m, h, w, q0 + k);
+      const int v = rle_val(m, h, rs, q0 + k);
       c += v != prev;
       prev = v;
     }
@@ -112,26 +112,30 @@ __global__ __launch_bounds__(256) void rle_count_kernel(const uint8_t* __restric
   if (threadIdx.x == 0) chunk_counts[(long)blockIdx.y * nchunks + blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(256) void rle_write_kernel(const uint8_t* __restrict__ masks, int h, int w, int nchunks,
+// POOLED = false: mask i writes positions[i * cap ...] and nruns[i] (the per-mask form).
+// POOLED = true : mask i writes pool[offsets[i] ...] (offsets = exclusive prefix of the masks' totals, rle_offsets_kernel);
+//                 cap = capacity of the whole pool.
+template <bool POOLED>
+__global__ __launch_bounds__(256) void rle_write_kernel(const uint8_t* __restrict__ masks, int h, int w, long ms, int rs, int nchunks,
                                                         const int* __restrict__ chunk_counts, int cap,
                                                         int* __restrict__ positions, int* __restrict__ nruns) {
   const long hw = (long)h * w;
-  const uint8_t* m = masks + (long)blockIdx.y * hw;
+  const uint8_t* m = masks + (long)blockIdx.y * ms;
   const int* cc = chunk_counts + (long)blockIdx.y * nchunks;
   __shared__ int scan[256];
   __shared__ int base;
   if (threadIdx.x == 0) {
     int b = 0;
     for (int i = 0; i < (int)blockIdx.x; ++i) b += cc[i];
-    base = b;
-    if (blockIdx.x == (unsigned)nchunks - 1) nruns[blockIdx.y] = b + cc[nchunks - 1];
+    if (!POOLED && blockIdx.x == (unsigned)nchunks - 1) nruns[blockIdx.y] = b + cc[nchunks - 1];
+    base = POOLED ? b + nruns[blockIdx.y] : b;        // (pooled: `nruns` holds the offsets)
   }
   const long q0 = (long)blockIdx.x * RLE_CHUNK + (long)threadIdx.x * 8;
   int flags = 0, c = 0;
   if (q0 < hw) {
-    int prev = q0 == 0 ? 0 : rle_val(m, h, w, q0 - 1);
+    int prev = q0 == 0 ? 0 : rle_val(m, h, rs, q0 - 1);
     for (int k = 0; k < 8 && q0 + k < hw; ++k) {
-      const int v = rle_val(m, h, w, q0 + k);
+      const int v = rle_val(m, h, rs, q0 + k);
       if (v != prev) { flags |= 1 << k; ++c; }
       prev = v;
     }
@@ -145,12 +149,31 @@ __global__ __launch_bounds__(256) void rle_write_kernel(const uint8_t* __restric
     __syncthreads();
   }
   int o = base + scan[threadIdx.x] - c;
-  int* dst = positions + (long)blockIdx.y * cap;
+  int* dst = POOLED ? positions : positions + (long)blockIdx.y * cap;
   for (int k = 0; k < 8; ++k)
     if (flags & (1 << k)) {
       if (o < cap) dst[o] = (int)(q0 + k);
       ++o;
     }
+}
+
+// offsets[0] = 0, offsets[i + 1] = offsets[i] + (boundaries of mask i): one workgroup; n is a few hundred masks of a chunk of frames
+__global__ __launch_bounds__(256) void rle_offsets_kernel(const int* __restrict__ chunk_counts, int n, int nchunks, int* __restrict__ offsets) {
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int* cc = chunk_counts + (long)i * nchunks;
+    int t = 0;
+    for (int k = 0; k < nchunks; ++k) t += cc[k];
+    offsets[i + 1] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    offsets[0] = 0;
+    for (int i = 0; i < n; ++i) {
+      run += offsets[i + 1];
+      offsets[i + 1] = run;
+    }
+  }
 }
 
 // 8 mask bytes -> 1 byte (bit k = mask[8i + k] != 0) and back: the masks a rank hands to the merge rank travel bit-packed
@@ -246,11 +269,32 @@ extern "C" int premvos_rle_boundaries_u8(const uint8_t* masks, int32_t n, int32_
   const int nchunks = (int)(((long)h * w + RLE_CHUNK - 1) / RLE_CHUNK);
   int* cc = static_cast<int*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(rle_count_kernel, dim3(nchunks, n), dim3(256), 0, s, masks, h, w, nchunks, cc);
+  hipLaunchKernelGGL(rle_count_kernel, dim3(nchunks, n), dim3(256), 0, s, masks, h, w, (long)h * w, w, nchunks, cc);
   int rc = premvos::check_launch("rle_count");
   if (rc) return rc;
-  hipLaunchKernelGGL(rle_write_kernel, dim3(nchunks, n), dim3(256), 0, s, masks, h, w, nchunks, cc, capacity, positions,
-                     nruns);
+  hipLaunchKernelGGL(rle_write_kernel<false>, dim3(nchunks, n), dim3(256), 0, s, masks, h, w, (long)h * w, w, nchunks, cc, capacity,
+                     positions, nruns);
+  return premvos::check_launch("rle_write");
+}
+
+extern "C" int premvos_rle_boundaries_pooled_u8(const uint8_t* masks, int32_t n, int32_t h, int32_t w, int64_t mask_stride,
+                                                int32_t row_stride, int32_t* pool, int32_t pool_capacity, int32_t* offsets,
+                                                void* workspace, void* stream) {
+  PV_REQUIRE(masks && pool && offsets && workspace, "rle_boundaries_pooled: null pointer");
+  PV_REQUIRE(n > 0 && n <= 65535 && h > 0 && w > 0 && pool_capacity > 0, "rle_boundaries_pooled: bad dims");
+  PV_REQUIRE(row_stride >= w && mask_stride >= (int64_t)(h - 1) * row_stride + w, "rle_boundaries_pooled: strides smaller than the mask");
+  PV_REQUIRE((long)h * w < (1L << 31), "rle_boundaries_pooled: mask too large");
+  const int nchunks = (int)(((long)h * w + RLE_CHUNK - 1) / RLE_CHUNK);
+  int* cc = static_cast<int*>(workspace);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(rle_count_kernel, dim3(nchunks, n), dim3(256), 0, s, masks, h, w, (long)mask_stride, row_stride, nchunks, cc);
+  int rc = premvos::check_launch("rle_count");
+  if (rc) return rc;
+  hipLaunchKernelGGL(rle_offsets_kernel, dim3(1), dim3(256), 0, s, cc, n, nchunks, offsets);
+  rc = premvos::check_launch("rle_offsets");
+  if (rc) return rc;
+  hipLaunchKernelGGL(rle_write_kernel<true>, dim3(nchunks, n), dim3(256), 0, s, masks, h, w, (long)mask_stride, row_stride, nchunks, cc,
+                     pool_capacity, pool, offsets);
   return premvos::check_launch("rle_write");
 }
 
@@ -272,5 +316,39 @@ extern "C" int64_t premvos_rle_counts_to_string_host(const int64_t* counts, int6
       out[p++] = (char)(c + 48);
     }
   }
+  return p;
+}
+
+// Host utility (no GPU): the "counts" strings of n masks from their pooled run boundaries (premvos_rle_boundaries_pooled_u8 after a
+// copy to the host): mask i's runs = successive differences of [0, pool[offsets[i]] ... pool[offsets[i+1] - 1], hw].  The strings are
+// written back to back into `out` (no terminators), str_offsets[i] .. str_offsets[i + 1] delimit string i.  Returns the total
+// length, or -1 if `cap` is too small.  One call per chunk of frames, the interpreter lock released for its duration.
+extern "C" int64_t premvos_rle_strings_host(const int32_t* pool, const int32_t* offsets, int32_t n, int64_t hw, char* out, int64_t cap,
+                                            int64_t* str_offsets) {
+  int64_t p = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    str_offsets[i] = p;
+    const int32_t* e = pool + offsets[i];
+    const int64_t m = (int64_t)offsets[i + 1] - offsets[i];
+    long long prev_edge = 0, c1 = 0, c2 = 0;      // c1 / c2: the run one / two back
+    for (int64_t k = 0; k <= m; ++k) {
+      const long long edge = k < m ? (long long)e[k] : (long long)hw;
+      const long long cnt = edge - prev_edge;
+      prev_edge = edge;
+      long long x = k > 2 ? cnt - c2 : cnt;
+      c2 = c1;
+      c1 = cnt;
+      bool more = true;
+      while (more) {
+        char c = (char)(x & 0x1f);
+        x >>= 5;
+        more = (c & 0x10) ? x != -1 : x != 0;
+        if (more) c |= 0x20;
+        if (p >= cap) return -1;
+        out[p++] = (char)(c + 48);
+      }
+    }
+  }
+  str_offsets[n] = p;
   return p;
 }

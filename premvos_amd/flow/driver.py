@@ -44,6 +44,24 @@ def writeFlowFile(filename: str, uv: np.ndarray) -> None:
         f.write(data)
 
 
+def write_flo_raw(filename: str, uv: np.ndarray) -> None:
+    """``writeFlowFile``'s bytes without building them first: the 12-byte header and the array's own memory in ONE ``writev`` (no
+    3.3 MB concatenation + copy per 480p file -- the merge rank of a gathered 8-GPU job writes ~430 of them per second)."""
+    if uv.ndim != 3 or uv.shape[2] != 2:
+        raise ValueError("writeFlowFile: flow must have two bands!")
+    if uv.dtype != np.float32 or not uv.flags.c_contiguous:
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+    head = np.array(TAG_FLOAT, dtype=np.float32).tobytes() + np.array([uv.shape[1], uv.shape[0]], dtype=np.int32).tobytes()
+    body = memoryview(uv).cast("B")
+    fd = os.open(filename, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        done = os.writev(fd, [head, body])
+        while done < len(head) + len(body):            # (a short write: finish the rest)
+            done += os.write(fd, head[done:] if done < len(head) else body[done - len(head):])
+    finally:
+        os.close(fd)
+
+
 def readFlowFile(filename: str) -> np.ndarray:
     """Reader with the consumer's semantics (MergeTrack/merge_functions.py:197-207)."""
     with open(filename, "rb") as f:

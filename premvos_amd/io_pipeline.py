@@ -98,40 +98,65 @@ def lanes(items: Iterable[A], work: Callable[[int, A], B], n: int = None) -> Ite
 
 
 class Writer:
-    """Runs ``fn(*args)`` calls on one background thread in submission order; ``close()`` waits and re-raises the first error."""
+    """Runs ``fn(*args)`` calls on background threads; ``close()`` waits and re-raises the first error.  One thread (the default of
+    the per-stage drivers): calls run in submission order.  ``threads`` > 1: the calls share one queue and may complete in any
+    order -- every call of this package writes its own file(s) and depends on no other call, so the tree is the same; the merge
+    rank of a gathered multi-GPU job needs that (it writes the files of EVERY rank: ~430 frames/s x (one 3.3 MB .flo + four JSON
+    files) at 8 ranks; file system calls, the RLE string packer and the JSON encoder's C core release or barely hold the
+    interpreter lock).  ``busy_s`` / ``max_depth`` / ``calls``: what the threads spent inside calls and how far the queue filled."""
 
     runs_callables = True                        # submit(fn) with no file argument is fine: any host work may be queued here
 
-    def __init__(self, enabled: bool = True, depth: int = 64):
+    def __init__(self, enabled: bool = True, depth: int = 64, threads: int = None):
         self._q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._err = None
-        self._thread = None
+        self._threads = []
+        self.busy_s, self.calls, self.max_depth = 0.0, 0, 0
+        self._stat_lock = threading.Lock()
         if enabled:
-            self._thread = threading.Thread(target=self._run, name="premvos-writer", daemon=True)
-            self._thread.start()
+            n = writer_threads() if threads is None else max(1, threads)
+            for i in range(n):
+                t = threading.Thread(target=self._run, name=f"premvos-writer{i}" if n > 1 else "premvos-writer", daemon=True)
+                t.start()
+                self._threads.append(t)
+
+    @property
+    def threads(self) -> int:
+        return len(self._threads)
 
     def _run(self):
+        import time
         while True:
             item = self._q.get()
             if item is None:
                 return
             if self._err is None:
+                t0 = time.perf_counter()
                 try:
                     item[0](*item[1])
                 except BaseException as e:          # noqa: BLE001 -- reported by close()
                     self._err = e
+                dt = time.perf_counter() - t0
+                with self._stat_lock:
+                    self.busy_s += dt
+                    self.calls += 1
 
     def submit(self, fn, *args):
-        if self._thread is None:
+        if not self._threads:
             fn(*args)
         else:
             self._q.put((fn, args))
+            d = self._q.qsize()
+            if d > self.max_depth:
+                self.max_depth = d
 
     def close(self):
-        if self._thread is not None:
-            self._q.put(None)
-            self._thread.join()
-            self._thread = None
+        if self._threads:
+            for _ in self._threads:
+                self._q.put(None)
+            for t in self._threads:
+                t.join()
+            self._threads = []
         if self._err is not None:
             raise self._err
 
@@ -145,3 +170,12 @@ class Writer:
             if exc[0] is None:                      # never replace an exception that is already in flight
                 raise
         return False
+
+
+def writer_threads(merge_rank: bool = False) -> int:
+    """File-writer threads of one rank: PREMVOS_IO_WRITERS, else 1 -- or, for the merge rank of a gathered job (it writes every
+    rank's files), up to 4 from this rank's share of the host."""
+    v = os.environ.get("PREMVOS_IO_WRITERS")
+    if v is not None:
+        return max(1, int(v))
+    return max(1, min(4, host_budget()["threads_per_rank"] // 4)) if merge_rank else 1

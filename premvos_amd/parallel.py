@@ -132,17 +132,26 @@ def gather_padded(local: torch.Tensor, n_valid: int, capacity: int, dst: int = 0
 
 class ResultExchange:
     """The one exchange of the path: every rank's per-step results go to the merge rank as ONE fixed-size byte buffer in
-    ONE gather -- flow [B,H,W,2] f32 | masks [B,P,H,W] bit-packed | boxes / scores / conf / counts f32.
+    ONE gather.  Layout (round 6: what the merge rank's HOST needs comes first, in one contiguous prefix):
 
-    ``pack_bits(masks_u8, out_bits_u8)`` / ``unpack_bits(bits_u8, out_masks_u8)`` default to the HIP kernels
-    (premvos_mask_pack_bits_u8 / premvos_mask_unpack_bits_u8); the CPU gloo tests inject numpy twins.  With the gloo backend
-    (CPU tests; several ranks sharing one GPU when exercising the logic by hand) the buffer is staged through the host.
+        flow [B,H,W,2] f32 | boxes / scores / conf / counts f32 | RLE offsets int32 [B*P + 1] | RLE pool int32 | masks [B,P,H,W] bit-packed
+
+    The run boundaries of every mask (column-major, the order COCO RLE counts them in) are found on the PRODUCING rank's GPU while
+    it packs (premvos_rle_boundaries_pooled_u8: one variable-length pool per chunk, ``rle_runs`` entries per mask slot on average),
+    so the merge rank turns a gathered buffer into files with one device-to-host copy of the prefix and host work only -- no
+    unpack, no kernel, no per-frame synchronisation on ITS GPU (round 5 did all of that there, for every rank's chunk; the reference
+    encodes on the CPU of whoever ran the net: FewShotSegmentationForwarder.py:137-143).  The bit-packed masks still travel: they
+    are what an in-process merge consumes (mergetrack.py) and the fallback when a chunk's boundaries overflow the pool.
+
+    ``pack_bits`` / ``unpack_bits`` / ``rle_pool`` default to the HIP kernels; the CPU gloo tests inject numpy twins.  With the gloo
+    backend (CPU tests; several ranks sharing one GPU when exercising the logic by hand) the buffer is staged through the host.
     """
 
     SMALL_COLS_FIXED = 2 * 20 * 5 + 2          # general + specific: 20 boxes x (4 + prob), + the two detection counts
 
     def __init__(self, batch: int, h: int, w: int, boxes_per_frame: int, device, dst: int = 0, group=None,
-                 pack_bits=None, unpack_bits=None, slots: int = 2):
+                 pack_bits=None, unpack_bits=None, slots: int = 2, rle_pool=None, rle_runs: Optional[int] = None):
+        import os
         self.B, self.H, self.W, self.P, self.dst, self.group = batch, h, w, boxes_per_frame, dst, group
         self.device = torch.device(device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -151,9 +160,17 @@ class ResultExchange:
         self.mask_bits = batch * boxes_per_frame * h * w
         self.mask_bytes = (self.mask_bits + 7) // 8
         self.small_cols = self.SMALL_COLS_FIXED + boxes_per_frame
-        self.off_mask = self.flow_bytes
-        self.off_small = (self.off_mask + self.mask_bytes + 15) // 16 * 16
-        self.nbytes = self.off_small + batch * self.small_cols * 4
+        self.n_masks = batch * boxes_per_frame
+        # boundaries per mask slot, on average over the chunk (an object mask of a 480p frame has a few hundred to ~2000; empty
+        # slots have none); a chunk that needs more sets offsets[-1] > pool_cap and is encoded from its masks on the merge rank
+        runs = int(os.environ.get("PREMVOS_GATHER_RLE_RUNS", "2048")) if rle_runs is None else rle_runs
+        self.pool_cap = max(16, self.n_masks * runs)
+        self.off_small = (self.flow_bytes + 15) // 16 * 16
+        self.off_rle_off = self.off_small + batch * self.small_cols * 4
+        self.off_rle_pool = (self.off_rle_off + (self.n_masks + 1) * 4 + 15) // 16 * 16
+        self.off_mask = (self.off_rle_pool + self.pool_cap * 4 + 15) // 16 * 16
+        self.prefix_bytes = self.off_mask           # everything the merge rank's host reads
+        self.nbytes = self.off_mask + (self.mask_bytes + 15) // 16 * 16
         # two slots: the gather of step i (async) is still reading slot i % 2 while step i + 1 is packed into the other one
         self._packed = [torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(slots)]
         self.packed = self._packed[0]
@@ -167,14 +184,28 @@ class ResultExchange:
         self._n = 0
         self.wait_s = 0.0          # seconds this rank spent blocked in wait() / flush() (bench.py: per-rank scaling diagnostics)
         self._pack_bits, self._unpack_bits = pack_bits or _hip_pack_bits, unpack_bits or _hip_unpack_bits
+        self._rle_pool = rle_pool or _hip_rle_pool
+        self._rle_ws = None
+
+    def _views(self, buf: torch.Tensor):
+        B = self.B
+        return (buf[:self.flow_bytes].view(torch.float32).view(B, self.H, self.W, 2),
+                buf[self.off_small:self.off_rle_off].view(torch.float32).view(B, self.small_cols),
+                buf[self.off_rle_off:self.off_rle_off + (self.n_masks + 1) * 4].view(torch.int32),
+                buf[self.off_rle_pool:self.off_rle_pool + self.pool_cap * 4].view(torch.int32),
+                buf[self.off_mask:self.off_mask + self.mask_bytes])
 
     def pack(self, r, slot: int = 0) -> torch.Tensor:
-        """r: the dict FramePipeline.step returns.  Fills and returns this rank's byte buffer."""
+        """r: the dict FramePipeline.step returns (``"hw"``: the frames' own size when it is smaller than the buffer's H x W --
+        the RLE runs over that window).  Fills and returns this rank's byte buffer."""
         B = self.B
         self.packed = self._packed[slot]
-        self.packed[:self.flow_bytes].view(torch.float32).view(B, self.H, self.W, 2).copy_(r["flow"])
-        self._pack_bits(r["masks"].contiguous().view(-1), self.packed[self.off_mask:self.off_mask + self.mask_bytes])
-        small = self.packed[self.off_small:].view(torch.float32).view(B, self.small_cols)
+        flow, small, roff, rpool, bits = self._views(self.packed)
+        flow.copy_(r["flow"])
+        masks = r["masks"].contiguous()
+        h, w = r.get("hw", (self.H, self.W))
+        self._rle_pool(masks.view(self.n_masks, self.H, self.W), int(h), int(w), rpool, roff, self)
+        self._pack_bits(masks.view(-1), bits)
         c = 0
         for key, n in (("general_boxes", 80), ("general_probs", 20), ("specific_boxes", 80), ("specific_probs", 20),
                        ("conf", self.P), ("general_count", 1), ("specific_count", 1)):
@@ -222,14 +253,21 @@ class ResultExchange:
     def gathered_slot(self, slot: int):
         return self._gathered[slot]
 
-    def unpack(self, buf: torch.Tensor):
-        """One rank's byte buffer -> dict of tensors (masks as {0,1} bytes), on ``buf``'s device."""
+    def unpack(self, buf: torch.Tensor, masks: bool = True):
+        """One rank's byte buffer -> dict of tensors on ``buf``'s device (``buf`` may be just the first ``prefix_bytes`` bytes when
+        ``masks`` is False: that is what the merge rank copies to its host).  ``masks``: also unpack the bit-packed masks to
+        {0,1} bytes (a kernel on the GPU).  ``rle_offsets`` [B*P + 1] / ``rle_pool``: mask slot i's ascending column-major run
+        boundaries are rle_pool[rle_offsets[i] : rle_offsets[i + 1]] -- valid unless rle_offsets[-1] > pool_cap."""
         B, P = self.B, self.P
         flow = buf[:self.flow_bytes].view(torch.float32).view(B, self.H, self.W, 2)
-        masks = torch.empty(self.mask_bits, dtype=torch.uint8, device=buf.device)
-        self._unpack_bits(buf[self.off_mask:self.off_mask + self.mask_bytes], masks)
-        small = buf[self.off_small:].view(torch.float32).view(B, self.small_cols)
-        out = {"flow": flow, "masks": masks.view(B, P, self.H, self.W)}
+        small = buf[self.off_small:self.off_rle_off].view(torch.float32).view(B, self.small_cols)
+        out = {"flow": flow,
+               "rle_offsets": buf[self.off_rle_off:self.off_rle_off + (self.n_masks + 1) * 4].view(torch.int32),
+               "rle_pool": buf[self.off_rle_pool:self.off_rle_pool + self.pool_cap * 4].view(torch.int32)}
+        if masks:
+            m = torch.empty(self.mask_bits, dtype=torch.uint8, device=buf.device)
+            self._unpack_bits(buf[self.off_mask:self.off_mask + self.mask_bytes], m)
+            out["masks"] = m.view(B, P, self.H, self.W)
         c = 0
         for key, n, shape in (("general_boxes", 80, (B, 20, 4)), ("general_probs", 20, (B, 20)), ("specific_boxes", 80, (B, 20, 4)),
                               ("specific_probs", 20, (B, 20)), ("conf", P, (B, P)), ("general_count", 1, (B,)),
@@ -238,6 +276,20 @@ class ResultExchange:
             c += n
         out["general_count"], out["specific_count"] = out["general_count"].to(torch.int32), out["specific_count"].to(torch.int32)
         return out
+
+
+def _hip_rle_pool(masks: torch.Tensor, h: int, w: int, pool: torch.Tensor, offsets: torch.Tensor, x: "ResultExchange"):
+    """masks uint8 [n, H, W] (CUDA): the run boundaries of every mask's h x w window -> pool / offsets (views of the packed buffer)."""
+    from . import _lib
+    _lib.require_gpu()
+    assert masks.is_cuda and pool.is_cuda and offsets.is_cuda and masks.dtype == torch.uint8
+    n, H, W = masks.shape
+    lib = _lib.load()
+    need = (int(lib.premvos_rle_workspace_bytes(n, h, w)) + 3) // 4
+    if x._rle_ws is None or x._rle_ws.numel() < need or x._rle_ws.device != masks.device:
+        x._rle_ws = torch.empty(need, dtype=torch.int32, device=masks.device)
+    _lib.check(lib.premvos_rle_boundaries_pooled_u8(masks.data_ptr(), n, h, w, H * W, W, pool.data_ptr(), pool.numel(),
+                                                    offsets.data_ptr(), x._rle_ws.data_ptr(), _lib.current_stream()), "rle_boundaries_pooled")
 
 
 def _hip_pack_bits(masks: torch.Tensor, out: torch.Tensor):

@@ -30,7 +30,7 @@ def combine(root_dir: str = "./output/intermediate/", one_dir: str = "general_pr
         out_file = f1.replace(one_dir, out_dir)
         os.makedirs(os.path.dirname(out_file), exist_ok=True)
         with open(out_file, "w") as f:
-            json.dump(fin, f)
+            f.write(json.dumps(fin))
     return len(files)
 
 

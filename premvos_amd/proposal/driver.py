@@ -257,7 +257,7 @@ def forward(pred_func, output_folder: str, forward_dataset: str, davis_name: Opt
 
     def dump(out_fn, js):
         with open(out_fn, "w") as f:
-            json.dump(js, f)
+            f.write(json.dumps(js))
 
     decoded = iop.prefetch(todo, load)            # JPEG decode runs ahead on a thread pool, JSON is written in the background
     n, held = 0, None

@@ -53,6 +53,29 @@ def counts_to_string(counts) -> str:
     return out.decode("ascii")
 
 
+def strings_from_pool(pool: np.ndarray, offsets: np.ndarray, hw: int) -> List[str]:
+    """The ``counts`` strings of len(offsets) - 1 masks from their POOLED run boundaries (premvos_rle_boundaries_pooled_u8 after the
+    copy to the host: mask i's ascending column-major change positions are pool[offsets[i]:offsets[i + 1]]; its run lengths are the
+    successive differences of [0, positions..., hw]) -- one call into the C twin for all of them (interpreter lock released)."""
+    import ctypes as C
+    from . import _lib
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    n = len(offsets) - 1
+    if n <= 0:
+        return []
+    first, last = int(offsets[0]), int(offsets[-1])
+    sub = np.ascontiguousarray(pool[first:last], dtype=np.int32)
+    rel = offsets - np.int32(first)
+    cap = 13 * (last - first + n) + 16                  # <= 13 characters per run (a 64-bit value in 5-bit groups)
+    buf = C.create_string_buffer(cap)
+    so = np.empty(n + 1, np.int64)
+    total = _lib.load().premvos_rle_strings_host(sub.ctypes.data, rel.ctypes.data, n, int(hw), buf, cap, so.ctypes.data)
+    if total < 0:
+        raise RuntimeError("premvos_rle_strings_host: output buffer too small")
+    text = buf.raw[:total].decode("ascii")
+    return [text[so[i]:so[i + 1]] for i in range(n)]
+
+
 def string_to_counts(s: str) -> List[int]:
     counts: List[int] = []
     p, b = 0, s.encode("ascii")

@@ -140,7 +140,7 @@ def convert_tree(src: str, dst: str) -> int:
         rel = os.path.splitext(os.path.relpath(fn, src))[0] + ".json"
         os.makedirs(os.path.dirname(os.path.join(dst, rel)), exist_ok=True)
         with open(os.path.join(dst, rel), "w") as f:
-            json.dump(to_proposals(read(fn)), f)
+            f.write(json.dumps(to_proposals(read(fn))))
         n += 1
     return n
 

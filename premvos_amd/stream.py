@@ -186,10 +186,7 @@ class StreamPipeline:
         gather.x.wait(slot)
         if gather.rank != gather.x.dst:
             return
-        bufs = gather.x.gathered_slot(slot)
-        for r in range(gather.world):
-            if k < len(gather.chunks[r]):
-                gather.decode_and_write(r, k, bufs[r], self.out, writer)
+        gather.decode_round(k, gather.x.gathered_slot(slot), self.out, writer)
 
     # ---- the driver ---------------------------------------------------------------------------------------------------
     def run_sequences(self, folders: List[str], shards: Optional[List[tuple]] = None, writer=None, gather: "Optional[DeviceGather]" = None) -> int:
@@ -198,7 +195,9 @@ class StreamPipeline:
         Returns the number of frames this process owned."""
         errors: List[BaseException] = []
         own_writer = writer is None
-        writer = iop.Writer(enabled=True) if own_writer else writer
+        if own_writer:                               # (the merge rank of a gathered job writes every rank's files: several threads)
+            merge = gather is not None and gather.world > 1 and gather.rank == gather.x.dst
+            writer = iop.Writer(enabled=True, threads=iop.writer_threads(merge_rank=True) if merge else None)
         ready: "queue.Queue" = queue.Queue()          # --gather: chunks whose four parts are in their staging block, as they complete
         free_stg: "queue.Queue" = queue.Queue()
         xthread = None
@@ -306,6 +305,7 @@ class StreamPipeline:
                             except queue.Empty:
                                 if errors or xdead.is_set() or not xthread.is_alive():
                                     raise RuntimeError("the exchange thread stopped before this chunk got a staging block")
+                        stg["hw"] = tuple(frames[0].shape[:2])          # (ResultExchange.pack: the RLE runs over the frames' own size)
                         left, lock, idx = {"flow", "general", "specific", "refine"}, threading.Lock(), n_chunks
 
                         def done(part, stg=stg, left=left, lock=lock, idx=idx):
@@ -388,16 +388,40 @@ def iter_chunks(images: List[str], first: int, end: Optional[int], batch: int, l
         yield chunk(cur, cur_names, None)
 
 
+_DIRS: set = set()
+
+
+def _mkdir_for(fn):
+    d = os.path.dirname(fn)
+    if d not in _DIRS:                          # (one stat per directory, not per file; a tree removed under a live process -- the
+        os.makedirs(d, exist_ok=True)           #  bench's repeated runs -- is handled by the retry in the two writers below)
+        _DIRS.add(d)
+
+
 def _dump_json(fn, obj):
-    os.makedirs(os.path.dirname(fn), exist_ok=True)
-    with open(fn, "w") as f:
-        json.dump(obj, f)
+    # json.dumps = the encoder's C core in one shot; json.dump(obj, f) walks the object in Python and writes token by token -- same
+    # text (FewShotSegmentationForwarder.py:151-155 / train.py:519-522 use json.dump), ~8x the time for a 40-proposal frame
+    text = json.dumps(obj)
+    _mkdir_for(fn)
+    try:
+        f = open(fn, "w")
+    except FileNotFoundError:
+        _DIRS.discard(os.path.dirname(fn))
+        _mkdir_for(fn)
+        f = open(fn, "w")
+    with f:
+        f.write(text)
 
 
 def _write_flo(fn, uv):
-    from .flow.driver import writeFlowFile
-    os.makedirs(os.path.dirname(fn), exist_ok=True)
-    writeFlowFile(fn, uv)
+    from .flow.driver import write_flo_raw
+    _mkdir_for(fn)
+    try:
+        write_flo_raw(fn, uv)
+    except FileNotFoundError:
+        _DIRS.discard(os.path.dirname(fn))
+        _mkdir_for(fn)
+        write_flo_raw(fn, uv)
 
 
 def _write_bytes(fn, data: bytes):
@@ -425,14 +449,17 @@ class DeviceGather:
     conf -- are packed on the device into ONE fixed-size buffer (premvos_amd.parallel.ResultExchange: masks bit-packed) and go to
     the merge rank in ONE asynchronous gather per round of chunks (double-buffered: the collective of round k runs while round
     k + 1 computes; ranks that own no chunk in a round send a filler).  The merge rank -- the one that will run MergeTrack --
-    decodes every rank's buffer (bit-unpack + RLE boundaries on ITS GPU, strings on its writer thread) and writes the files: the
-    same bytes the per-rank writers produce, because proposal JSON, conf strings and RLE are pure functions of the gathered
-    arrays (tests/test_gpu_plumbing.py compares the trees).  Round 3 gathered host-packed file bytes per shard item instead."""
+    turns every rank's buffer into files: the same bytes the per-rank writers produce, because proposal JSON, conf strings and RLE
+    are pure functions of the gathered arrays (tests/test_gpu_plumbing.py compares the trees).  Round 6: the run boundaries of the
+    masks are found by the PRODUCING rank while it packs and travel in the buffer, so the merge rank's share per chunk is one
+    device-to-host copy + host work on several writer threads (``decode_round``) -- at 8 ranks it ingests ~430 frames/s beside
+    its own chunks (profiles/r06_merge_ingest.json; round 5 unpacked and re-encoded every rank's masks on the merge rank's GPU and
+    fed ONE writer thread).  Round 3 gathered host-packed file bytes per shard item instead."""
 
     P = 40                       # combined proposals per frame: 20 general + 20 specific (config.py:123)
 
     def __init__(self, pipe: "StreamPipeline", folders: List[str], plans: List[List[tuple]], rank: int, world: int, device,
-                 pack_bits=None, unpack_bits=None):
+                 pack_bits=None, unpack_bits=None, rle_pool=None):
         from PIL import Image
         from .parallel import ResultExchange
         self.pipe, self.rank, self.world = pipe, rank, world
@@ -452,10 +479,13 @@ class DeviceGather:
         hm = max([hw[0] for hw in sizes.values()] + [8])
         wm = max([hw[1] for hw in sizes.values()] + [8])
         self.hm, self.wm = hm, wm
-        self.x = ResultExchange(pipe.batch, hm, wm, self.P, device, pack_bits=pack_bits, unpack_bits=unpack_bits)
+        self.x = ResultExchange(pipe.batch, hm, wm, self.P, device, pack_bits=pack_bits, unpack_bits=unpack_bits, rle_pool=rle_pool)
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:      # taken on the constructing (main) thread: the exchange thread
             self.device = torch.device("cuda", torch.cuda.current_device())   # selects THIS device, whatever its own default is
+        self._free: "queue.Queue" = queue.Queue()    # page-locked host buffers (one chunk's prefix each), returned by the writer threads
+        self._n_host, self._host_lock = 0, threading.Lock()
+        self.rle_overflows = 0                       # chunks whose run boundaries did not fit the pool (encoded from the masks instead)
 
     def staging(self) -> dict:
         """The ``r`` dict of one chunk (ResultExchange.pack's input), zero-filled, at the job's largest frame size."""
@@ -470,48 +500,122 @@ class DeviceGather:
                 "specific_probs": torch.zeros((B, 20), dtype=torch.float32, device=dev),
                 "specific_count": torch.zeros((B,), dtype=torch.int32, device=dev)}
 
-    def decode_and_write(self, r: int, k: int, buf: torch.Tensor, out: str, writer) -> int:
-        """Merge rank: rank ``r``'s buffer of round ``k`` -> its files.  Returns the number of files submitted."""
-        from .mergetrack import encode_masks_begin, encode_masks_finish
-        from .proposal.driver import custom_resize_shape, results_json
+    # ---- the merge rank's side ------------------------------------------------------------------------------------------
+    def _take_host(self, writer) -> torch.Tensor:
+        """A page-locked host buffer for one chunk's prefix (flow, detections, conf, run boundaries): from the pool the writer
+        threads return them to, or a new one while fewer than 2 x world + 2 exist (a round in flight + a round being written)."""
+        import time
+        while True:
+            try:
+                return self._free.get_nowait()
+            except queue.Empty:
+                pass
+            with self._host_lock:
+                grow = self._n_host < 2 * self.world + 2
+                if grow:
+                    self._n_host += 1
+            if grow:
+                t = torch.empty(self.x.prefix_bytes, dtype=torch.uint8)
+                return t.pin_memory() if self.device.type == "cuda" else t
+            try:
+                return self._free.get(timeout=0.5)
+            except queue.Empty:                       # (only the writer threads return buffers: do not outwait their failure)
+                if getattr(writer, "_err", None) is not None:
+                    raise RuntimeError("the file writer failed while chunks were waiting for host buffers") from writer._err
+            time.sleep(0)
+
+    def decode_round(self, k: int, bufs, out: str, writer) -> int:
+        """Merge rank: every rank's buffer of round ``k`` -> files.  Returns the number of files submitted.
+
+        What this rank's GPU and this (exchange) thread do per chunk: ONE device-to-host copy of the buffer's prefix into page-locked
+        memory (the copies of a round are queued back to back, one synchronisation) -- the run boundaries of the masks were found
+        by the producing rank.  Everything else is host work per FRAME on the writer threads (``_finish_frame``): the .flo straight
+        from the page-locked buffer, the proposal JSON from the detection arrays, the RLE strings from the run boundaries.  The
+        same bytes the per-rank writers produce (tests/test_gpu_plumbing.py compares the trees; MergeTrack/merge.py:66-67,126-128
+        and FewShotSegmentationForwarder.py:137-155 are what this hand-over replaces)."""
+        live = [r for r in range(self.world) if k < len(self.chunks[r])]
+        host = {}
+        for r in live:
+            host[r] = self._take_host(writer)
+            host[r].copy_(bufs[r][:self.x.prefix_bytes], non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        return sum(self.decode_and_write(r, k, bufs[r], out, writer, host[r]) for r in live)
+
+    def decode_and_write(self, r: int, k: int, buf: torch.Tensor, out: str, writer, host: Optional[torch.Tensor] = None) -> int:
+        """Merge rank: rank ``r``'s buffer of round ``k`` -> its files (``host``: the prefix, already on the host).  Returns the
+        number of files submitted."""
+        from .mergetrack import encode_masks_begin
+        from .proposal.driver import custom_resize_shape
         seq, names, has_next, (h, w) = self.chunks[r][k]
         n = len(names)
-        u = self.x.unpack(buf)
-        files = 0
-        # (copies: on the host-staged path .cpu().numpy() is a VIEW of the gather slot, which the gather two rounds on overwrites
-        #  while the asynchronous writer may still hold these arrays)
-        flow = u["flow"][:n, :h, :w].cpu().numpy()
-        for i in range(n - (0 if has_next else 1)):
-            writer.submit(_write_flo, os.path.join(out, "flow", seq, names[i] + ".flo"), np.array(flow[i], copy=True, order="C"))
-            files += 1
+        if host is None:
+            host = self._take_host(writer)
+            host.copy_(buf[:self.x.prefix_bytes])
+        u = self.x.unpack(host, masks=False)
+        view = {key: t.numpy() for key, t in u.items()}
         nh, nw = custom_resize_shape(h, w)
         scale = (nh * 1.0 / h + nw * 1.0 / w) / 2
-        lists = {}
-        for which in ("general", "specific"):
-            lists[which] = results_json(u[which + "_boxes"][:n].cpu().numpy(), u[which + "_probs"][:n].cpu().numpy(),
-                                        u[which + "_count"][:n].cpu().numpy(), scale, (h, w))
+        handles = [None] * n
+        if int(view["rle_offsets"][-1]) > self.x.pool_cap:
+            # more run boundaries than the pool holds (very ragged masks): this chunk is encoded from its masks, here
+            self.rle_overflows += 1
+            dev = buf if buf.is_cuda else buf.to(self.device)
+            masks = self.x.unpack(dev)["masks"]
             for i in range(n):
-                writer.submit(_dump_json, os.path.join(out, which + "_proposals", seq, names[i] + ".json"), lists[which][i])
-                files += 1
-        conf = u["conf"][:n].cpu().numpy().copy()
-        masks = u["masks"]
-        if not masks.is_cuda:
-            masks = masks.to("cuda")
+                cnt = int(view["general_count"][i]) + int(view["specific_count"][i])
+                if cnt:
+                    handles[i] = encode_masks_begin(masks[i, :cnt, :h, :w].contiguous())
+        lease = _Lease(host, self._free, n)
         for i in range(n):
-            both = lists["general"][i] + lists["specific"][i]
-            writer.submit(_dump_json, os.path.join(out, "combined_proposals", seq, names[i] + ".json"), both)
-            refined = [dict(p) for p in both]
-            handle = encode_masks_begin(masks[i, :len(both), :h, :w].contiguous()) if both else None
+            writer.submit(self._finish_frame, lease, view, i, seq, names[i], h, w, scale, has_next or i < n - 1, out, handles[i])
+        return 5 * n - (0 if has_next else 1)
 
-            def finish(refined=refined, handle=handle, c=conf[i], fn=os.path.join(out, "refined_proposals", seq, names[i] + ".json")):
+    def _finish_frame(self, lease, view, i, seq, name, h, w, scale, write_flow, out, handle):
+        """Writer thread: the five files of one frame from the host copy of its chunk's buffer."""
+        from . import rle
+        from .mergetrack import encode_masks_finish
+        from .proposal.driver import results_json
+        try:
+            if write_flow:
+                _write_flo(os.path.join(out, "flow", seq, name + ".flo"), view["flow"][i, :h, :w])
+            lists = {}
+            for which in ("general", "specific"):
+                lists[which] = results_json(view[which + "_boxes"][i:i + 1], view[which + "_probs"][i:i + 1],
+                                            view[which + "_count"][i:i + 1], scale, (h, w))[0]
+                _dump_json(os.path.join(out, which + "_proposals", seq, name + ".json"), lists[which])
+            both = lists["general"] + lists["specific"]
+            _dump_json(os.path.join(out, "combined_proposals", seq, name + ".json"), both)
+            refined = [dict(p) for p in both]
+            if both:
                 if handle is not None:
-                    for q, seg, cv in zip(refined, encode_masks_finish(handle), c):
-                        q["segmentation"] = seg
-                        q["conf_score"] = str(cv)
-                _dump_json(fn, refined)
-            writer.submit(finish)
-            files += 2
-        return files
+                    segs = encode_masks_finish(handle)
+                else:
+                    first = i * self.P
+                    strings = rle.strings_from_pool(view["rle_pool"], view["rle_offsets"][first:first + len(both) + 1], h * w)
+                    segs = [{"size": [h, w], "counts": c} for c in strings]
+                for q, seg, cv in zip(refined, segs, view["conf"][i]):
+                    q["segmentation"] = seg
+                    q["conf_score"] = str(cv)
+            _dump_json(os.path.join(out, "refined_proposals", seq, name + ".json"), refined)
+        finally:
+            lease.done()
+
+
+class _Lease:
+    """A host buffer shared by the per-frame writer calls of one chunk; the last one returns it to the pool."""
+
+    def __init__(self, buf, pool: "queue.Queue", parts: int):
+        self.buf, self._pool, self._left, self._lock = buf, pool, parts, threading.Lock()
+        if parts <= 0:
+            pool.put(buf)
+
+    def done(self):
+        with self._lock:
+            self._left -= 1
+            last = self._left == 0
+        if last:
+            self._pool.put(self.buf)
 
 
 def _self_launch(gpus: int, argv: List[str]) -> int:

@@ -69,6 +69,40 @@ def _np_unpack_bits(bits, out):
     out.copy_(torch.from_numpy(np.unpackbits(bits.numpy(), bitorder="little")[:out.numel()]))
 
 
+def _np_rle_pool(masks, h, w, pool, offsets, x):
+    """numpy twin of premvos_rle_boundaries_pooled_u8: ascending column-major change positions of every mask's h x w window."""
+    import numpy as np
+    m = masks.numpy()
+    run, off, cap = 0, [0], pool.numel()
+    for i in range(m.shape[0]):
+        flat = (m[i, :h, :w] != 0).reshape(-1, order="F").astype(np.int8)
+        pos = np.flatnonzero(np.diff(np.concatenate(([0], flat)))).astype(np.int32)
+        keep = pos[:max(0, min(len(pos), cap - run))]
+        pool[run:run + len(keep)] = torch.from_numpy(keep)
+        run += len(pos)
+        off.append(run)
+    offsets.copy_(torch.tensor(off, dtype=torch.int32))
+
+
+def _xchg(B, H, W, P_, **kw):
+    return P.ResultExchange(B, H, W, P_, "cpu", pack_bits=_np_pack_bits, unpack_bits=_np_unpack_bits, rle_pool=_np_rle_pool, **kw)
+
+
+def _check_rle(u, ref, x):
+    """The run boundaries a buffer carries decode to the masks it carries (premvos_amd.rle's own reader as the witness)."""
+    import numpy as np
+    from premvos_amd import rle
+    off, pool = u["rle_offsets"].numpy(), u["rle_pool"].numpy()
+    assert off[0] == 0 and off[-1] <= x.pool_cap
+    masks = ref["masks"].numpy().reshape(x.n_masks, x.H, x.W)
+    for i in range(x.n_masks):
+        edges = np.concatenate(([0], pool[off[i]:off[i + 1]].astype(np.int64), [x.H * x.W]))
+        back = rle.decode({"size": [x.H, x.W], "counts": [int(c) for c in np.diff(edges)]})
+        if not np.array_equal(back, masks[i]):
+            return False
+    return True
+
+
 def _fake_results(rank, B, P_, H, W):
     g = torch.Generator().manual_seed(100 + rank)
     return {"flow": torch.randn((B, H, W, 2), generator=g), "masks": (torch.rand((B, P_, H, W), generator=g) > 0.6).to(torch.uint8),
@@ -83,7 +117,7 @@ def _xchg_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     B, P_, H, W = 2, 3, 5, 7               # 2*3*5*7 = 210 mask bits: not a multiple of 8
-    x = P.ResultExchange(B, H, W, P_, "cpu", pack_bits=_np_pack_bits, unpack_bits=_np_unpack_bits)
+    x = _xchg(B, H, W, P_)
     calls = {"n": 0}
     real_gather = dist.gather
 
@@ -99,7 +133,7 @@ def _xchg_worker(rank, world, port, q):
         ok = len(got) == world
         for r in range(world):
             ref, u = _fake_results(r, B, P_, H, W), x.unpack(got[r])
-            ok = ok and all(torch.equal(u[k], ref[k]) for k in ref)
+            ok = ok and all(torch.equal(u[k], ref[k]) for k in ref) and _check_rle(u, ref, x)
         q.put(ok)
     else:
         assert got is None
@@ -123,10 +157,43 @@ def test_result_exchange_single_packed_gather_world2_gloo():
 
 
 def test_result_exchange_layout_is_fixed_size_and_bit_packed():
-    x = P.ResultExchange(16, 480, 854, 20, "cpu", pack_bits=_np_pack_bits, unpack_bits=_np_unpack_bits)
+    x = _xchg(16, 480, 854, 20)
     assert x.flow_bytes == 16 * 480 * 854 * 2 * 4 and x.mask_bytes == 16 * 20 * 480 * 854 // 8
-    assert x.off_small % 16 == 0 and x.nbytes == x.off_small + 16 * (2 * 20 * 5 + 2 + 20) * 4
-    assert x.nbytes < 0.16 * (x.flow_bytes + 16 * 20 * 480 * 854 + 16 * 222 * 4) + x.flow_bytes      # masks shrink 8x
+    # what the merge rank's HOST reads is one contiguous prefix -- flow, detections / conf / counts, run-boundary offsets + pool --
+    # and the bit-packed masks come last
+    assert x.off_small % 16 == 0 and x.off_rle_off == x.off_small + 16 * (2 * 20 * 5 + 2 + 20) * 4
+    assert x.off_rle_pool % 16 == 0 and x.off_rle_pool >= x.off_rle_off + (16 * 20 + 1) * 4
+    assert x.off_mask % 16 == 0 and x.off_mask == x.prefix_bytes >= x.off_rle_pool + x.pool_cap * 4
+    assert x.pool_cap == 16 * 20 * 2048 and x.nbytes == x.off_mask + x.mask_bytes
+    assert x.nbytes < 0.16 * (x.flow_bytes + 16 * 20 * 480 * 854 + 16 * 222 * 4) + x.flow_bytes + 4 * x.pool_cap + 4096   # masks shrink 8x
+
+
+def test_result_exchange_run_boundaries_window_overflow_and_strings():
+    """The pooled run boundaries a buffer carries: over the frames' own h x w window of a larger block, flagged (offsets[-1] >
+    pool_cap) when the pool is too small, and turned into COCO strings by the C packer exactly as rle.encode does from the mask."""
+    import numpy as np
+    from premvos_amd import rle
+    B, P_, H, W, h, w = 2, 3, 9, 11, 7, 8
+    r = _fake_results(5, B, P_, H, W)
+    r["masks"][0, 0] = 0                                     # an empty slot: one run
+    r["masks"][0, 1] = 1                                     # all foreground: the first run has length 0
+    r["hw"] = (h, w)
+    x = _xchg(B, H, W, P_, rle_runs=64)
+    u = x.unpack(x.exchange(r)[0])
+    off, pool = u["rle_offsets"].numpy(), u["rle_pool"].numpy()
+    assert off[-1] <= x.pool_cap
+    strings = rle.strings_from_pool(pool, off, h * w)
+    m = r["masks"].numpy().reshape(B * P_, H, W)[:, :h, :w]
+    for i in range(B * P_):
+        assert strings[i] == rle.encode(m[i])["counts"], i
+        assert np.array_equal(rle.decode({"size": [h, w], "counts": strings[i]}), m[i])
+    # a window of the strings (the slots of one frame), as the merge rank asks for them
+    assert rle.strings_from_pool(pool, off[P_:2 * P_ + 1], h * w) == strings[P_:]
+    assert rle.strings_from_pool(pool, off[:1], h * w) == []
+    # too small a pool: the total still says how many there were
+    y = _xchg(B, H, W, P_, rle_runs=1)
+    v = y.unpack(y.exchange(r)[0])
+    assert int(v["rle_offsets"][-1]) == int(off[-1]) > y.pool_cap
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -220,7 +287,7 @@ def _async_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     B, P_, H, W = 2, 3, 5, 7
-    x = P.ResultExchange(B, H, W, P_, "cpu", pack_bits=_np_pack_bits, unpack_bits=_np_unpack_bits)
+    x = _xchg(B, H, W, P_)
     ok, slots = True, []
     for step in range(5):                   # double-buffered: the gather of step i is waited for when slot i % 2 comes round again
         slots.append(x.exchange_async(_fake_results(10 * step + rank, B, P_, H, W)))
@@ -293,7 +360,7 @@ def _strong_worker(rank, world, port, q, T, B):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     P_, H, W = 3, 5, 7
-    x = P.ResultExchange(B, H, W, P_, "cpu", pack_bits=_np_pack_bits, unpack_bits=_np_unpack_bits)
+    x = _xchg(B, H, W, P_)
     plans = [P.plan_shards([T], world, r, B) for r in range(world)]
     chunks = [[c0 // B for _, s0, e0 in p for c0 in range(s0, e0, B)] for p in plans]      # chunk ids per rank
     rounds = max(len(c) for c in chunks)

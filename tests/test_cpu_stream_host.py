@@ -112,3 +112,126 @@ def test_a_decode_error_on_the_producer_thread_ends_every_thread(tmp_path, monke
     q, _ = _fake_pipeline(batch=4)
     (tmp_path / "b").mkdir()
     assert q.run_sequences([_tree(tmp_path / "b", 5)], writer=BadWriter()) == 5         # a caller-owned writer is closed by the caller
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the merge rank's side of --gather, entirely on the host: a packed buffer -> the five files per frame
+def _np_twins():
+    import torch
+    from test_cpu_parallel import _np_pack_bits, _np_rle_pool, _np_unpack_bits
+    return {"pack_bits": _np_pack_bits, "unpack_bits": _np_unpack_bits, "rle_pool": _np_rle_pool}, torch
+
+
+@pytest.mark.parametrize("writers,overflow", [(1, False), (3, False), (2, True)])
+def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, monkeypatch, writers, overflow):
+    """DeviceGather.decode_round (round 6: run boundaries from the producing rank, per-frame host work on N writer threads, buffers
+    leased from a pool) against a straightforward per-frame restatement of what a rank's own writers produce: flo_bytes of the flow
+    window, results_json of the detections, rle.encode of every mask, str(conf).  ``overflow``: a pool too small for the chunk --
+    the masks themselves are used (the GPU encoder is replaced by its numpy twin here)."""
+    import json as js
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    twins, torch = _np_twins()
+    from premvos_amd import io_pipeline as iop
+    from premvos_amd import mergetrack, rle
+    from premvos_amd.flow.driver import flo_bytes
+    from premvos_amd.proposal.driver import custom_resize_shape, results_json
+    from PIL import Image
+    h, w, B, T = 21, 30, 4, 7                      # two chunks: 4 + 3 frames; the second one ends the video (no .flo for its last frame)
+    d = tmp_path / "JPEGImages" / "clip"
+    d.mkdir(parents=True)
+    for t in range(T):
+        Image.fromarray(np.full((h, w, 3), t, np.uint8)).save(d / f"{t:05d}.png")
+    pipe = type("P", (), {"batch": B})()
+    monkeypatch.setenv("PREMVOS_GATHER_RLE_RUNS", "1" if overflow else "1024")
+    if overflow:                                   # (the fallback encodes on the GPU: its numpy twin stands in)
+        def begin(m):
+            m = m.numpy()
+            rows = [np.flatnonzero(np.diff(np.concatenate(([0], (x != 0).reshape(-1, order="F").astype(np.int8))))) for x in m]
+            width = max([len(r) for r in rows] + [1])
+            pos = np.zeros((len(rows), width), np.int32)
+            for i, r in enumerate(rows):
+                pos[i, :len(r)] = r
+            return pos, np.array([len(r) for r in rows], np.int32), m.shape[1], m.shape[2]
+        monkeypatch.setattr(mergetrack, "encode_masks_begin", begin)
+    dg = stream.DeviceGather(pipe, [str(d) + "/"], [[(0, 0, T)]], 0, 1, "cpu", **twins)
+    assert dg.rounds == 2 and dg.chunks[0][1][2] is False
+    rng = np.random.default_rng(3)
+    out = str(tmp_path / "out")
+    expect = {}
+    with iop.Writer(threads=writers) as wr:
+        for k, (seq, names, has_next, hw) in enumerate(dg.chunks[0]):
+            n = len(names)
+            r = dg.staging()
+            r["hw"] = (h, w)
+            r["flow"][:n] = torch.from_numpy(rng.standard_normal((n, h, w, 2)).astype(np.float32))
+            gc, sc = rng.integers(0, 4, n), rng.integers(0, 4, n)
+            r["general_count"][:n], r["specific_count"][:n] = torch.from_numpy(gc.astype(np.int32)), torch.from_numpy(sc.astype(np.int32))
+            for key in ("general", "specific"):
+                xy = rng.uniform(0, 40, (n, 20, 2)).astype(np.float32)
+                r[key + "_boxes"][:n] = torch.from_numpy(np.concatenate([xy, xy + rng.uniform(1, 60, (n, 20, 2)).astype(np.float32)], -1))
+                r[key + "_probs"][:n] = torch.from_numpy(rng.uniform(0.5, 1, (n, 20)).astype(np.float32))
+            r["conf"][:n] = torch.from_numpy(rng.uniform(-1, 1, (n, dg.P)).astype(np.float32))
+            r["masks"][:n] = torch.from_numpy((rng.random((n, dg.P, h, w)) > 0.55).astype(np.uint8))
+            slot = dg.x.exchange_async(r)
+            dg.x.wait(slot)
+            assert dg.decode_round(k, dg.x.gathered_slot(slot), out, wr) == 5 * n - (0 if has_next else 1)
+            # the restatement (what the producing rank's own writers would have written)
+            nh, nw = custom_resize_shape(h, w)
+            scale = (nh * 1.0 / h + nw * 1.0 / w) / 2
+            g = results_json(r["general_boxes"][:n].numpy(), r["general_probs"][:n].numpy(), gc, scale, (h, w))
+            s = results_json(r["specific_boxes"][:n].numpy(), r["specific_probs"][:n].numpy(), sc, scale, (h, w))
+            for i, name in enumerate(names):
+                if has_next or i < n - 1:
+                    expect[f"flow/{seq}/{name}.flo"] = flo_bytes(r["flow"][i].numpy())
+                both = g[i] + s[i]
+                expect[f"general_proposals/{seq}/{name}.json"] = js.dumps(g[i]).encode()
+                expect[f"specific_proposals/{seq}/{name}.json"] = js.dumps(s[i]).encode()
+                expect[f"combined_proposals/{seq}/{name}.json"] = js.dumps(both).encode()
+                ref = [dict(p) for p in both]
+                for j, q in enumerate(ref):
+                    q["segmentation"] = rle.encode(r["masks"][i, j].numpy())
+                    q["conf_score"] = str(r["conf"][i, j].numpy())
+                expect[f"refined_proposals/{seq}/{name}.json"] = js.dumps(ref).encode()
+    assert dg.rle_overflows == (2 if overflow else 0)
+    got = {}
+    for root, _, files in os.walk(out):
+        for f in files:
+            fn = os.path.join(root, f)
+            got[os.path.relpath(fn, out)] = open(fn, "rb").read()
+    assert sorted(got) == sorted(expect) and len(got) == 5 * T - 1
+    for key in expect:
+        assert got[key] == expect[key], key
+    assert dg._free.qsize() == dg._n_host <= 4           # every leased host buffer came back
+
+
+def test_writer_threads_run_every_call_count_their_time_and_report_the_first_error():
+    from premvos_amd import io_pipeline as iop
+    done, lock = [], threading.Lock()
+
+    def work(i):
+        time.sleep(0.002)
+        with lock:
+            done.append(i)
+    wr = iop.Writer(threads=3, depth=4)
+    assert wr.threads == 3
+    for i in range(40):
+        wr.submit(work, i)
+    wr.close()
+    assert sorted(done) == list(range(40)) and wr.calls == 40 and wr.busy_s >= 0.07 and 1 <= wr.max_depth <= 4
+    one = iop.Writer(threads=1)
+    order = []
+    for i in range(20):
+        one.submit(order.append, i)
+    one.close()
+    assert order == list(range(20))                       # one thread: submission order, as before
+
+    def boom():
+        raise ValueError("disk full")
+    bad = iop.Writer(threads=2)
+    bad.submit(boom)
+    for i in range(5):
+        bad.submit(work, i)
+    with pytest.raises(ValueError):
+        bad.close()
+    assert iop.writer_threads() == 1 and 1 <= iop.writer_threads(merge_rank=True) <= 4

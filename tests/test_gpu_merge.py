@@ -181,3 +181,78 @@ def test_mask_warp_vs_reference_executed_warp_proposals():
         assert o["score"] == w["score"] and o["id"] == w["id"] and o["object_score"] == w["object_score"]
         assert np.array_equal(np.asarray(o["bbox"], np.float64), bb) and np.array_equal(np.asarray(o["mask"]), wm)
         assert isinstance(o["segmentation"]["counts"], str)
+
+
+@pytest.mark.parametrize("shape", [(6, 9, 11, 9, 11), (5, 21, 30, 17, 26), (40, 480, 854, 480, 854), (3, 64, 40, 1, 1)])
+def test_pooled_run_boundaries_and_the_host_string_packer(shape):
+    """premvos_rle_boundaries_pooled_u8 (round 6: a chunk's masks -> ONE variable-length pool, on the rank that produced them; the
+    h x w window of masks that sit in a larger block) + premvos_rle_strings_host: the strings are rle.encode's (the numpy reader of
+    the same format), the per-mask kernel agrees, an all-zero and an all-one mask are covered, and a pool that is too small says so."""
+    from premvos_amd import _lib, mergetrack as MT
+    n, H, W, h, w = shape
+    rng = np.random.default_rng(n * 1000 + h)
+    big = np.zeros((n, H, W), np.uint8)
+    blobs = _masks(n + 1, n, H, W) if min(H, W) >= 8 else (rng.random((n, H, W)) > 0.5).astype(np.uint8)
+    big[:] = blobs * rng.integers(1, 255, (n, 1, 1)).astype(np.uint8)         # any non-zero byte is foreground
+    big[0] = 0
+    if n > 1:
+        big[1] = 7
+    if n > 2:
+        big[2] = (rng.random((H, W)) > 0.5)                                    # a very ragged one
+    m = torch.from_numpy(big).cuda()
+    lib = _lib.load()
+    cap = int(sum(len(rle.counts_from_mask(big[i, :h, :w])) for i in range(n))) + 8
+    pool = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+    off = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+    ws = torch.empty((int(lib.premvos_rle_workspace_bytes(n, h, w)) + 3) // 4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.premvos_rle_boundaries_pooled_u8(m.data_ptr(), n, h, w, H * W, W, pool.data_ptr(), cap, off.data_ptr(), ws.data_ptr(),
+                                                    _lib.current_stream()), "pooled")
+    o, p = off.cpu().numpy(), pool.cpu().numpy()
+    assert o[0] == 0 and np.all(np.diff(o) >= 0) and o[-1] <= cap and np.all(p[o[-1]:] == -1)
+    strings = rle.strings_from_pool(p, o, h * w)
+    for i in range(n):
+        win = big[i, :h, :w]
+        assert strings[i] == rle.encode(win)["counts"], i
+        pos = p[o[i]:o[i + 1]]
+        assert np.all(np.diff(pos) > 0) if len(pos) > 1 else True
+    if (H, W) == (h, w):                                                       # the per-mask kernel of round 2: same boundaries
+        segs = MT.encode_masks(m)
+        assert [s["counts"] for s in segs] == strings
+    # a pool that cannot hold the chunk: offsets[-1] still reports the need, nothing is written past the capacity
+    small = max(1, int(o[-1]) // 2)
+    pool2 = torch.full((small + 4,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.premvos_rle_boundaries_pooled_u8(m.data_ptr(), n, h, w, H * W, W, pool2.data_ptr(), small, off.data_ptr(), ws.data_ptr(),
+                                                    _lib.current_stream()), "pooled")
+    assert int(off[-1]) == int(o[-1]) and np.all(pool2.cpu().numpy()[small:] == -1)
+    assert np.array_equal(pool2.cpu().numpy()[:min(small, int(o[-1]))], p[:min(small, int(o[-1]))])
+
+
+def test_merge_ingest_tool_reproduces_the_one_rank_tree_at_small_size(tmp_path, monkeypatch):
+    """tools/time_merge_ingest.py (bench.py's `merge_ingest` leg) end to end on small frames and reduced nets: three fake ranks,
+    recorded buffers replayed alone and beside the real streaming driver, and the round-5 form of the merge side -- every tree
+    byte-identical to the one-rank tree (``measure`` raises otherwise)."""
+    import importlib.util
+    import os
+    from oracle import proposal_oracle as PO, pwc_oracle as O, refinement_oracle as RO
+    from premvos_amd import stream
+    spec = importlib.util.spec_from_file_location("time_merge_ingest", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "time_merge_ingest.py"))
+    tmi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tmi)
+    monkeypatch.setenv("PREMVOS_DRIVER_BATCH", "2")
+    monkeypatch.setenv("PREMVOS_IO_WRITERS", "3")
+    job = tmi.build_job(str(tmp_path / "job"), 7, 3, h=120, w=200, weights=False)      # 7 frames, chunks of 3: a ragged last chunk
+    wd = tmp_path / "w"
+    wd.mkdir()
+    torch.save({"state_dict": O.synth_state_dict(0)}, wd / "pwc.pth.tar")
+    torch.save(PO.synth_weights(0, (1, 1, 2, 1)), wd / "general.pt")
+    torch.save(PO.synth_weights(1, (1, 1, 2, 1)), wd / "specific.pt")
+    torch.save(RO.synth_weights(0, 1), wd / "refine.pt")
+    sp = stream.StreamPipeline(str(wd / "pwc.pth.tar"), str(wd / "general.pt"), str(wd / "specific.pt"), str(wd / "refine.pt"),
+                               batch=3, out=str(tmp_path / "out"))
+    for legacy in (False, True):
+        rep = tmi.measure(sp, job["clips"], 7, 3, legacy=legacy, tmp_out=str(tmp_path / f"t{int(legacy)}"))
+        for mode in ("alone", "beside"):
+            assert rep[mode]["byte_identical_trees"] and rep[mode]["files"] == 3 * (5 * 7 - 1), rep
+            assert rep[mode]["rle_overflow_chunks"] == 0
+        assert rep["writer_threads"] == (1 if legacy else 3)
