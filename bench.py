@@ -60,9 +60,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=int(os.environ.get("PREMVOS_BENCH_FRAMES", "0")),
                     help="strong scaling: frame pairs of the video (default 8 chunks = 8 x --batch: one chunk per GPU of an 8-GPU node per pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--supplementary", default=os.environ.get("PREMVOS_BENCH_SUPPLEMENTARY", "mixed-bf16x3,1080p"),
+    ap.add_argument("--supplementary", default=os.environ.get("PREMVOS_BENCH_SUPPLEMENTARY", "mixed-bf16x3,1080p,1080p-mixed-bf16x3"),
                     help="after the fp32 line's timed region (N = 1, 480p, fp32 only): short passes of these further modes, measured by "
-                         "this same run into the `supplementary` object -- comma-separated from {mixed-bf16x3, 1080p}; 'none' skips")
+                         "this same run into the `supplementary` object -- comma-separated from {mixed-bf16x3, 1080p, 1080p-mixed-bf16x3}; 'none' skips")
     ap.add_argument("--cpu-baseline-worker", default=None, metavar="K:CORES", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--file-to-file", type=int, default=int(os.environ.get("PREMVOS_BENCH_F2F_FRAMES", "128")), metavar="FRAMES",
@@ -259,11 +259,36 @@ class BoxSampler:
             except Exception:                  # noqa: BLE001 -- (already initialised by another object of this process)
                 pass
             hs = amdsmi.amdsmi_get_processor_handles()
-            self.h = hs[index % len(hs)]
+            self.h, self.matched_by = self._pick(hs, index)
             self._read()                       # fail here, not in the thread
         except Exception as e:                 # noqa: BLE001
             self.err = f"{type(e).__name__}: {e}"[:200]
         self.th = threading.Thread(target=self._loop, daemon=True)
+
+    def _pick(self, handles, index):
+        """The amdsmi handle of HIP device ``index``.  amdsmi lists every physical GPU and ignores HIP_VISIBLE_DEVICES /
+        ROCR_VISIBLE_DEVICES, so the HIP index is not its position: match by PCI address (domain:bus:device) -- and refuse to
+        describe some other GPU when nothing matches.  Builds that expose no PCI address fall back to the position."""
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = (int(pr.pci_domain_id), int(pr.pci_bus_id), int(pr.pci_device_id))
+        except Exception:                      # noqa: BLE001 -- no GPU (CPU tests) or a build without the PCI fields
+            pass
+        if want is None or not hasattr(self.smi, "amdsmi_get_gpu_device_bdf"):
+            return handles[index % len(handles)], "position (no PCI address available)"
+        seen = []
+        for h in handles:
+            try:
+                bdf = str(self.smi.amdsmi_get_gpu_device_bdf(h))          # "0000:c1:00.0"
+                dom, bus, rest = bdf.split(":")
+                got = (int(dom, 16), int(bus, 16), int(rest.split(".")[0], 16))
+            except Exception:                  # noqa: BLE001
+                continue
+            seen.append(bdf)
+            if got == want:
+                return h, "pci " + bdf
+        raise RuntimeError(f"no amdsmi device at PCI {want[0]:04x}:{want[1]:02x}:{want[2]:02x} (HIP device {index}); amdsmi lists {seen}")
 
     def _read(self):
         m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
@@ -298,7 +323,7 @@ class BoxSampler:
         col = lambda i: [s[i] for s in self.samples if s[i] is not None]        # noqa: E731
         stat = lambda v, nd=0: {"min": round(min(v), nd), "mean": round(sum(v) / len(v), nd), "max": round(max(v), nd)} if v else None   # noqa: E731
         ppt, acc = col(6), col(7)
-        return {"samples": len(self.samples), "period_s": self.period,
+        return {"samples": len(self.samples), "period_s": self.period, "device_matched_by": getattr(self, "matched_by", None),
                 "sclk_mhz_mean_of_xcds": stat(col(0)), "sclk_mhz_slowest_xcd": stat(col(1)), "socket_power_w": stat(col(2)),
                 "temperature_hotspot_c": stat(col(3)), "temperature_mem_c": stat(col(4)), "uclk_mhz": stat(col(5)),
                 # share of the region the firmware reports as power-limited (PPT residency counter / accumulation counter)
@@ -535,8 +560,8 @@ def supplementary_pass(mode: str, B: int, dev, passes: int = 3) -> dict:
     bars, tests/test_gpu_error_budget.py); ``1080p``: configs[4]'s frame shape in fp32.  Never the metric's line."""
     from premvos_amd import synth
     from premvos_amd.pipeline import FramePipeline
-    h, w = (1080, 1920) if mode == "1080p" else (480, 854)
-    net_prec, flow_prec = ("bf16x3", "fp32") if mode == "mixed-bf16x3" else ("fp32", "fp32")
+    h, w = (1080, 1920) if mode.startswith("1080p") else (480, 854)
+    net_prec, flow_prec = ("bf16x3", "fp32") if mode.endswith("mixed-bf16x3") else ("fp32", "fp32")
     t_build = time.perf_counter()
     pipe = FramePipeline(synth.pwc_state_dict(0), synth.proposal_weights(0), synth.proposal_weights(1), synth.refinement_weights(0),
                          batch=B, device=str(dev), boxes_per_frame=P_BOXES, precision=net_prec, flow_precision=flow_prec)
@@ -562,7 +587,7 @@ def supplementary_pass(mode: str, B: int, dev, passes: int = 3) -> dict:
             "per_stage_tflops", "conv_ms_per_step", "launches_per_step", "note")
     box = smi.summary()
     out = {"value": round(passes * n_launch * B / dt, 2), "unit": "frames/s", "frame": f"{h}x{w}",
-           "dtype": "flow f32; proposal+refinement bf16x3 (split-fp32 on the bf16 MFMA pipe, f32 accumulate)" if mode == "mixed-bf16x3" else "f32",
+           "dtype": "flow f32; proposal+refinement bf16x3 (split-fp32 on the bf16 MFMA pipe, f32 accumulate)" if net_prec == "bf16x3" else "f32",
            "ms_per_launch": round(1e3 * dt / (passes * n_launch), 2), "frames_per_launch": B, "launches_timed": passes * n_launch,
            "build_and_first_pass_s": round(t_build, 1), "measured_by_this_run": True,
            "roofline": {k: rf[k] for k in keep if k in rf},
@@ -801,7 +826,23 @@ def main():
         from premvos_amd import ops
         out["conv_configurations"] = ops.tune_info()     # which table / rule froze the kernels (reproducibility)
         if not a.no_roofline:
-            out["roofline"] = roofline(pipe, B, net_prec, flow_prec)
+            out["roofline"] = rf = roofline(pipe, B, net_prec, flow_prec)
+            # ... beside the per-layer replay above (each layer back to back with itself: warm L2 / MALL, one stream): the WHOLE launch as
+            # the timed region ran it -- every kernel of B frames (depthwise, RoIAlign, cost volume, resizes, NMS ... included), five
+            # streams -- priced against the same peak: B x gflop_per_frame / (this rank's seconds per launch)
+            n_launch = len(chunks) if strong else 1
+            if n_launch and net_prec == "fp32":
+                ms_launch = 1e3 * dt_own / a.steps / n_launch
+                gf = out["config"]["gflop_per_frame"]
+                peak = rf["peak"]
+                rf["whole_step_ms_per_launch"] = round(ms_launch, 3)
+                rf["whole_step_tflops"] = round(B * gf * 1e9 / (ms_launch * 1e-3) / 1e12, 2)
+                rf["whole_step_frac"] = round(B * gf * 1e9 / (ms_launch * 1e-3) / 1e12 / peak, 4)
+                rf["non_conv_ms_per_launch"] = round(ms_launch - rf["conv_ms_per_step"], 3)
+                rf["whole_step_is"] = ("B x config.gflop_per_frame (algorithmic, all kernels) / this rank's wall time per launch in the timed "
+                                       "region / peak; non_conv_ms_per_launch = that wall time - conv_ms_per_step (the serial replay of the "
+                                       "dense convs): depthwise, RoIAlign, cost volume, resizes, selection kernels and what the five-stream "
+                                       "overlap does not hide")
         # secondary: the same path measured FILE TO FILE (JPEG decode, .flo / JSON / COCO-RLE writing included) by the streaming
         # driver -- by THIS run at N = 1, after the timed region; `value` above is the HBM-resident metric, never this
         if world == 1 and a.frame == "480p" and a.file_to_file > 0 and prec == "fp32":
@@ -812,7 +853,7 @@ def main():
             except Exception as e:           # noqa: BLE001 -- a secondary leg must not take the contract line down
                 out["file_to_file"] = {"error": f"{type(e).__name__}: {e}"[:300], "measured_by_this_run": False}
         # supplementary modes under the same run's clock (never `value`): the fp32 object is freed first
-        modes = [m for m in a.supplementary.split(",") if m in ("mixed-bf16x3", "1080p")]
+        modes = [m for m in a.supplementary.split(",") if m in ("mixed-bf16x3", "1080p", "1080p-mixed-bf16x3")]
         if world == 1 and a.frame == "480p" and prec == "fp32" and modes:
             pipe = step = fa = fb = boxes = None
             if strong:

@@ -162,6 +162,20 @@ def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def resolve_device(device=None) -> "torch.device":
+    """``device`` with its INDEX: None / "cuda" / an index-less torch.device mean "the calling thread's current GPU" -- which is a
+    per-thread setting (a new thread starts on device 0), so an object that keeps such a value and is later used from another thread
+    would allocate on another GPU.  Every constructor / helper of this package resolves the device ONCE, here, on the thread that
+    calls it, and passes the indexed device on (tests/test_cpu_device_discipline.py: no bare "cuda" elsewhere in premvos_amd/).
+    A tensor stands for its own device.  Without a visible GPU the value passes through (host-only tests)."""
+    if isinstance(device, torch.Tensor):
+        device = device.device
+    d = torch.device("cuda" if device is None else device)
+    if d.type == "cuda" and d.index is None and torch.cuda.is_available():
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise PremvosError("no GPU visible: premvos_amd runs only on the HIP path (no CPU fallback)")

@@ -77,13 +77,13 @@ class FlowStage:
     """uint8 frame pairs [B,H,W,3] (RGB, on the GPU) -> flow [B,H,W,2] fp32 (the .flo payload)."""
 
     def __init__(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, batch: int = 1,
-                 device: str = "cuda", net: Optional[PWCDCNet] = None, use_graph: bool = True,
+                 device=None, net: Optional[PWCDCNet] = None, use_graph: bool = True,
                  precision: Optional[str] = None):
         _lib.require_gpu()
         self.net = net if net is not None else PWCDCNet(device=device, use_graph=False, precision=precision)
         if state_dict is not None:
             self.net.load_state_dict(state_dict)
-        self.batch, self.device, self.use_graph = batch, device, use_graph
+        self.batch, self.device, self.use_graph = batch, (self.net.device if net is not None and device is None else _lib.resolve_device(device)), use_graph
         self._shape = None
 
     def _prepare(self, h: int, w: int):

@@ -207,10 +207,10 @@ class _Plan:
 class PWCDCNet:
     """Drop-in for ``models.PWCNet.PWCDCNet`` (inference).  ``__call__`` == ``forward`` in eval mode."""
 
-    def __init__(self, md: int = 4, device: str = "cuda", use_graph: bool = True, precision: Optional[str] = None):
+    def __init__(self, md: int = 4, device=None, use_graph: bool = True, precision: Optional[str] = None):
         assert md == MD, "PWC-Net is instantiated with md=4 (PWCNet.py:43)"
         self.precision = precision or ops.default_precision()
-        self.device = device
+        self.device = _lib.resolve_device(device)
         self.use_graph = use_graph
         self.training = False
         self.packed: Dict[str, ops.PackedConv] = {}
@@ -283,7 +283,7 @@ class PWCDCNet:
     __call__ = forward
 
 
-def pwc_dc_net(path: Optional[str] = None, device: str = "cuda", use_graph: bool = True,
+def pwc_dc_net(path: Optional[str] = None, device=None, use_graph: bool = True,
                precision: Optional[str] = None) -> PWCDCNet:
     """models/PWCNet.py:496-505."""
     model = PWCDCNet(device=device, use_graph=use_graph, precision=precision)

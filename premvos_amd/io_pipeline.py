@@ -27,6 +27,39 @@ A = TypeVar("A")
 B = TypeVar("B")
 
 
+def creator_device():
+    """Index of the calling thread's current GPU, or None on a host without one.  "The current device" is a per-thread setting and a
+    new thread starts on device 0: every thread this package starts selects its CREATOR's device before it runs anything
+    (``start_thread`` / ``thread_pool`` below are the only places in premvos_amd/ that create threads --
+    tests/test_cpu_device_discipline.py), so "the current stream" / an index-less allocation inside a stage, lane, exchange, decode or
+    writer thread of a LOCAL_RANK > 0 process means that rank's GPU, not GPU 0."""
+    import torch
+    return torch.cuda.current_device() if torch.cuda.is_available() else None
+
+
+def bind_device(index) -> None:
+    if index is not None:
+        import torch
+        torch.cuda.set_device(index)
+
+
+def start_thread(target: Callable[[], None], name: str, daemon: bool = True) -> threading.Thread:
+    """``threading.Thread(target).start()`` whose first action is to select the creating thread's GPU."""
+    dev = creator_device()
+
+    def run():
+        bind_device(dev)
+        target()
+    t = threading.Thread(target=run, name=name, daemon=daemon)
+    t.start()
+    return t
+
+
+def thread_pool(workers: int, prefix: str) -> ThreadPoolExecutor:
+    """A ``ThreadPoolExecutor`` whose workers select the creating thread's GPU when they start."""
+    return ThreadPoolExecutor(max_workers=workers, thread_name_prefix=prefix, initializer=bind_device, initargs=(creator_device(),))
+
+
 def host_budget(cpus: int = None, world: int = None) -> dict:
     """Host threads of ONE rank of a one-process-per-GPU job, sized from the threads the node has per rank
     (``os.cpu_count() // LOCAL_WORLD_SIZE``; the ranks of a node share its cores).  A rank of the streaming driver runs
@@ -66,7 +99,7 @@ def prefetch(jobs: Iterable[A], load: Callable[[A], B], workers: int = None, dep
         return
     depth = depth or 2 * workers
     pending = collections.deque()
-    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="premvos-load") as pool:
+    with thread_pool(workers, "premvos-load") as pool:
         for j in jobs:
             pending.append(pool.submit(load, j))
             if len(pending) >= depth:
@@ -83,7 +116,7 @@ def lanes(items: Iterable[A], work: Callable[[int, A], B], n: int = None) -> Ite
         for it in items:
             yield work(0, it)
         return
-    pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"premvos-lane{i}") for i in range(n)]
+    pools = [thread_pool(1, f"premvos-lane{i}") for i in range(n)]
     pending = collections.deque()
     try:
         for k, it in enumerate(items):
@@ -116,9 +149,7 @@ class Writer:
         if enabled:
             n = writer_threads() if threads is None else max(1, threads)
             for i in range(n):
-                t = threading.Thread(target=self._run, name=f"premvos-writer{i}" if n > 1 else "premvos-writer", daemon=True)
-                t.start()
-                self._threads.append(t)
+                self._threads.append(start_thread(self._run, f"premvos-writer{i}" if n > 1 else "premvos-writer"))
 
     @property
     def threads(self) -> int:

@@ -114,8 +114,9 @@ def entropy_decode(data: bytes) -> Decoded:
     return Decoded(info, coef)
 
 
-def reconstruct(d: Decoded, device="cuda", bgr: bool = False) -> torch.Tensor:
+def reconstruct(d: Decoded, device=None, bgr: bool = False) -> torch.Tensor:
     """Upload the coefficients and run the two kernels on the current stream of ``device``: uint8 [H,W,3]."""
+    device = _lib.resolve_device(device)
     _lib.require_gpu()
     lib, info = _lib.load(), d.info
     if d.coef is None:
@@ -134,7 +135,7 @@ def reconstruct(d: Decoded, device="cuda", bgr: bool = False) -> torch.Tensor:
     return out
 
 
-def decode(data: bytes, device="cuda", bgr: bool = False) -> torch.Tensor:
+def decode(data: bytes, device=None, bgr: bool = False) -> torch.Tensor:
     return reconstruct(entropy_decode(data), device, bgr)
 
 
@@ -158,23 +159,23 @@ def host_stage(src: Union[str, bytes]) -> Union[Decoded, np.ndarray]:
         return _pil_rgb(data)
 
 
-def device_stage(item: Union[Decoded, np.ndarray], device="cuda", bgr: bool = False) -> torch.Tensor:
+def device_stage(item: Union[Decoded, np.ndarray], device=None, bgr: bool = False) -> torch.Tensor:
     """uint8 [H,W,3] in HBM on the current stream, RGB (or BGR, the cv2.imread order)."""
     if isinstance(item, Decoded):
         return reconstruct(item, device, bgr)
-    t = torch.from_numpy(item).to(device)
+    t = torch.from_numpy(item).to(_lib.resolve_device(device))
     return t.flip(2).contiguous() if bgr else t
 
 
-def imread(src: Union[str, bytes], device="cuda", bgr: bool = False) -> torch.Tensor:
+def imread(src: Union[str, bytes], device=None, bgr: bool = False) -> torch.Tensor:
     return device_stage(host_stage(src), device, bgr)
 
 
-def to_device(item, device="cuda", bgr: bool = False) -> torch.Tensor:
+def to_device(item, device=None, bgr: bool = False) -> torch.Tensor:
     """One frame as the drivers hold it -- a host RGB array, a ``Decoded`` (entropy-decoded, not yet reconstructed) or a uint8 tensor
     already in HBM -- as uint8 [H,W,3] on ``device`` (current stream)."""
     if isinstance(item, torch.Tensor):
-        t = item if item.is_cuda else item.to(device)
+        t = item if item.is_cuda else item.to(_lib.resolve_device(device))
         if item.is_cuda:
             # decoded on another stream (and complete: its producer synchronised); tell the allocator this stream reads it too,
             # so the block is not handed out again while a kernel of this stream is still in flight
@@ -185,11 +186,11 @@ def to_device(item, device="cuda", bgr: bool = False) -> torch.Tensor:
     return device_stage(np.array(item[:, :, :3], dtype=np.uint8, order="C"), device, bgr)
 
 
-def stack_frames(items, device="cuda", bgr: bool = False) -> torch.Tensor:
+def stack_frames(items, device=None, bgr: bool = False) -> torch.Tensor:
     """Frames of equal size -> uint8 [n,H,W,3] on ``device``: ONE upload for host arrays, the GPU decode for ``Decoded`` items."""
     items = list(items)
     if all(isinstance(i, np.ndarray) for i in items):
-        t = torch.from_numpy(np.stack([np.array(i[:, :, :3], dtype=np.uint8, order="C") for i in items])).to(device)
+        t = torch.from_numpy(np.stack([np.array(i[:, :, :3], dtype=np.uint8, order="C") for i in items])).to(_lib.resolve_device(device))
         return t.flip(3).contiguous() if bgr else t
     return torch.stack([to_device(i, device, bgr) for i in items])
 

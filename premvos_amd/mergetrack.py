@@ -22,8 +22,9 @@ from . import _lib, rle
 ArrayLike = Union[np.ndarray, torch.Tensor]
 
 
-def _dev_masks(masks, device="cuda") -> torch.Tensor:
-    """-> uint8 [n,h,w] contiguous CUDA tensor."""
+def _dev_masks(masks, device=None) -> torch.Tensor:
+    """-> uint8 [n,h,w] contiguous CUDA tensor: masks that are in HBM stay on THEIR device; host masks go to ``device`` (default: the
+    calling thread's current GPU)."""
     if isinstance(masks, torch.Tensor):
         t = masks
     else:
@@ -32,7 +33,7 @@ def _dev_masks(masks, device="cuda") -> torch.Tensor:
     if t.dim() == 2:
         t = t.unsqueeze(0)
     assert t.dim() == 3, t.shape
-    return t.to(device=device, dtype=torch.uint8).contiguous()
+    return t.to(device=t.device if t.is_cuda else _lib.resolve_device(device), dtype=torch.uint8).contiguous()
 
 
 def get_flow(filename: str) -> np.ndarray:

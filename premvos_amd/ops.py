@@ -37,9 +37,9 @@ class NHWC:
         assert 0 <= coff and coff + self.c <= self.ps
 
     @staticmethod
-    def alloc(n: int, h: int, w: int, c: int, device="cuda", ps: Optional[int] = None) -> "NHWC":
+    def alloc(n: int, h: int, w: int, c: int, device=None, ps: Optional[int] = None) -> "NHWC":
         ps = _r(c, 4) if ps is None else ps
-        return NHWC(torch.zeros((n, h, w, ps), dtype=torch.float32, device=device), c=c)
+        return NHWC(torch.zeros((n, h, w, ps), dtype=torch.float32, device=_lib.resolve_device(device)), c=c)
 
     def slice(self, coff: int, c: int) -> "NHWC":
         assert self.layout == "f32" or (coff % 8 == 0 and c % 8 == 0), "an S8 window starts and ends on a group of 8 channels"
@@ -49,8 +49,8 @@ class NHWC:
         return NHWC(self.buf[n0:n0 + n], c=self.c, coff=self.coff, layout=self.layout)
 
     @staticmethod
-    def alloc_s8(n: int, h: int, w: int, c: int, device="cuda") -> "NHWC":
-        v = NHWC(torch.zeros((n, h, w, _r(c, 8)), dtype=torch.float32, device=device), c=c, layout="s8")
+    def alloc_s8(n: int, h: int, w: int, c: int, device=None) -> "NHWC":
+        v = NHWC(torch.zeros((n, h, w, _r(c, 8)), dtype=torch.float32, device=_lib.resolve_device(device)), c=c, layout="s8")
         return v
 
     @property
@@ -90,12 +90,13 @@ def default_precision() -> str:
     return os.environ.get("PREMVOS_PRECISION", "fp32")
 
 
-def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None,
               scale: Optional[torch.Tensor] = None, precision: str = "fp32", wino4_min_c: Optional[int] = None) -> PackedConv:
     """OIHW fp32 -> [cout_pad][k_pad] with k = (kh*KW+kw)*cin_pad + c.  ``scale`` (per cout)
     folds a frozen BatchNorm's gamma/sqrt(var+eps) into the weights.  precision 'bf16' / 'bf16x3': the matrix
     is stored as bfloat16 high parts (+ low parts w - float(hi)) and k is padded to 32."""
     prec = _lib.PRECISIONS[precision]
+    device = _lib.resolve_device(device)
     w = weight.detach().to(torch.float32).cpu()
     cout, cin, kh, kw = w.shape
     if scale is not None:
@@ -176,7 +177,7 @@ def pack_winograd(w_oihw: torch.Tensor, cin_pad: int, cout_pad: int, device="cpu
     return out
 
 
-def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
+def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None,
                      precision: str = "fp32") -> PackedConv:
     """ConvTranspose2d(k=4,s=2,p=1) weights [cin,cout,4,4] -> the equivalent 3x3 conv with
     4*cout phase outputs (phase = 2*py+px writes out[2y+py][2x+px]).  For output row 2y+py the
@@ -198,7 +199,7 @@ def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device=
     return pk
 
 
-def pack_deconv2x2s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
+def pack_deconv2x2s2(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None,
                      precision: str = "fp32") -> PackedConv:
     """ConvTranspose2d(k=2,s=2) (tensorpack Deconv2D(…, 2, stride=2), proposal_net/model.py:507): the taps do not
     overlap, so it is a 1x1 conv with 4*cout phase outputs (phase = 2*ky+kx writes out[2y+ky][2x+kx])."""
@@ -265,8 +266,9 @@ def workspace_bytes(d: ConvDesc) -> int:
     return int(_lib.load().premvos_conv2d_workspace_bytes(C.byref(d)))
 
 
-def assign_workspace(descs, device="cuda") -> Optional[torch.Tensor]:
+def assign_workspace(descs, device=None) -> Optional[torch.Tensor]:
     """One split-K scratch buffer shared by all convs of a (stream-ordered) launch list."""
+    device = _lib.resolve_device(device)
     need = max([workspace_bytes(d) for d in descs] + [0])
     if need == 0:
         return None
@@ -515,7 +517,7 @@ def _entry_for(d: ConvDesc):
 
 def _out_digest(d: ConvDesc, lib, stream) -> int:
     """64-bit digest of the output window a launch of ``d`` wrote (premvos_digest_u64), on the host."""
-    buf = torch.zeros(1, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(1, dtype=torch.int64, device=_lib.resolve_device())      # (autotune runs on the plan builder's thread and device)
     w = d.cout if d.out_mode == OUT_NHWC else d.cout_ps
     px = d.n * d.ho * d.wo * (1 if d.out_mode == OUT_NHWC else 4)
     _lib.check(lib.premvos_digest_u64(d.out, px, w, d.out_ps, buf.data_ptr(), stream), "digest")
@@ -606,7 +608,7 @@ def _polish(descs, device, lib, stream):
                 _TUNE_STATE["explored"] += 1
 
 
-def autotune(descs, device="cuda", reps: int = 4):
+def autotune(descs, device=None, reps: int = 4):
     """Freeze a (kernel family, tile, stage depth, k-split, tail split) configuration into every descriptor.
 
     Where the choice comes from, in this order (PREMVOS_AUTOTUNE=1, the default):
@@ -622,6 +624,7 @@ def autotune(descs, device="cuda", reps: int = 4):
     mode = os.environ.get("PREMVOS_AUTOTUNE", "1")
     if mode == "0" or not torch.cuda.is_available():
         return
+    device = _lib.resolve_device(device)
     reps = int(os.environ.get("PREMVOS_AUTOTUNE_REPS", reps))      # launches per timing burst (tools/make_tune_table.py --reps)
     force = os.environ.get("PREMVOS_FORCE_KERNEL")          # diagnostics (tests/test_gpu_error_budget.py): every layer that CAN
     if force:                                                # run on this family does, whatever the table says
@@ -699,9 +702,10 @@ class PackedConvS8:
     cout_pad: int
 
 
-def pack_conv_s8(weight: torch.Tensor, bias: Optional[torch.Tensor], device="cuda", scale: Optional[torch.Tensor] = None) -> PackedConvS8:
+def pack_conv_s8(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None, scale: Optional[torch.Tensor] = None) -> PackedConvS8:
     """OIHW fp32 -> the S8 operand layout: row n = output channel, then (tap, block of 32 input channels, group of 8, hi | lo), zero
     padded; w = hi + lo with hi = bf16(w), lo = bf16(w - hi).  ``scale`` folds a frozen BatchNorm's gamma / sqrt(var + eps) in."""
+    device = _lib.resolve_device(device)
     w = weight.detach().to(torch.float32).cpu()
     cout, cin, kh, kw = w.shape
     if scale is not None:

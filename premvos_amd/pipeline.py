@@ -12,6 +12,7 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from . import _lib
 from .flow.driver import FlowStage
 from .proposal.driver import ProposalStage
 from .proposal.model import RESNET_NUM_BLOCK, RESULTS_PER_IM
@@ -21,10 +22,11 @@ from .refinement.model import RefinementNet
 class FramePipeline:
     def __init__(self, flow_sd: Dict[str, torch.Tensor], prop_general: Dict[str, object],
                  prop_specific: Dict[str, object], refine_w: Dict[str, object], batch: int = 1,
-                 device: str = "cuda", boxes_per_frame: int = RESULTS_PER_IM,
+                 device=None, boxes_per_frame: int = RESULTS_PER_IM,
                  num_blocks: Sequence[int] = RESNET_NUM_BLOCK, num_middle: int = 16, concurrent: bool = True,
                  precision: Optional[str] = None, flow_precision: Optional[str] = None):
-        self.batch, self.device, self.P = batch, device, boxes_per_frame
+        self.batch, self.device, self.P = batch, _lib.resolve_device(device), boxes_per_frame
+        device = self.device
         self.precision = precision
         self.flow = FlowStage(flow_sd, batch=batch, device=device, precision=flow_precision or precision)
         self.prop_g = ProposalStage(prop_general, batch=batch, device=device, num_blocks=num_blocks, rgb_input=True,

@@ -63,12 +63,12 @@ class OfflinePredictor:
 class ProposalStage:
     """Raw uint8 BGR frames [B,H,W,3] on the device -> device-resident detections, resize fused on the GPU."""
 
-    def __init__(self, weights: Dict[str, object], batch: int = 1, device: str = "cuda",
+    def __init__(self, weights: Dict[str, object], batch: int = 1, device=None,
                  num_blocks: Sequence[int] = RESNET_NUM_BLOCK, net: Optional[ProposalNet] = None,
                  use_graph: bool = True, rgb_input: bool = False, precision: Optional[str] = None):
         self.net = net if net is not None else ProposalNet(weights, num_blocks, device, use_graph=False,
                                                            precision=precision)
-        self.batch, self.device, self.use_graph = batch, device, use_graph
+        self.batch, self.device, self.use_graph = batch, (self.net.device if net is not None and device is None else _lib.resolve_device(device)), use_graph
         self.rgb_input = rgb_input
         self._shape = None
 

@@ -290,12 +290,13 @@ class ProposalNet:
     beta, mean, var), 'rpn/{conv0,class,box}/{W,b}', 'fastrcnn/{class,box}/{W,b}', 'secondclassification/class/{W,b}'."""
 
     def __init__(self, weights: Dict[str, object], num_blocks: Sequence[int] = RESNET_NUM_BLOCK,
-                 device: str = "cuda", use_graph: bool = True, precision: Optional[str] = None,
+                 device=None, use_graph: bool = True, precision: Optional[str] = None,
                  mode_mask: bool = False):
         _lib.require_gpu()
         self.mode_mask = mode_mask
         self.precision = prec = precision or ops.default_precision()
-        self.device, self.use_graph, self.num_blocks = device, use_graph, tuple(num_blocks)
+        self.device, self.use_graph, self.num_blocks = _lib.resolve_device(device), use_graph, tuple(num_blocks)
+        device = self.device
         self.packed: Dict[str, ops.PackedConv] = {}
         self._plans: Dict[tuple, _Plan] = {}
         self.cell_anchors_dev = torch.from_numpy(cell_anchors()).to(device)

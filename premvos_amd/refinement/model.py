@@ -343,11 +343,12 @@ class RefinementNet:
     '<scope>/weights' OIHW, '<scope>/depthwise_weights' [C,1,3,3], '<scope>/BatchNorm' = dict(gamma,beta,mean,var),
     'logits/features/biases'."""
 
-    def __init__(self, weights: Dict[str, object], num_middle: int = 16, device: str = "cuda", use_graph: bool = True,
+    def __init__(self, weights: Dict[str, object], num_middle: int = 16, device=None, use_graph: bool = True,
                  precision: Optional[str] = None):
         _lib.require_gpu()
         self.precision = prec = precision or ops.default_precision()
-        self.device, self.use_graph, self.num_middle = device, use_graph, num_middle
+        self.device, self.use_graph, self.num_middle = _lib.resolve_device(device), use_graph, num_middle
+        device = self.device
         self.packed: Dict[str, ops.PackedConv] = {}
         self.packed_s8: Dict[str, ops.PackedConvS8] = {}     # bf16x3 mode: the convs whose input is resident in the S8 layout
         self.packed_dw: Dict[str, PackedDW] = {}

@@ -165,11 +165,12 @@ class ReIDNet:
     """``weights``: TF variable names of the ReID graph -> '<layer>/W' conv OIHW | FC [out, in(NHWC-flattened)],
     '<layer>/b', '<layer>/bn*' = dict(gamma, beta, mean, var)  (mean_ema / var_ema in the checkpoint)."""
 
-    def __init__(self, weights: Dict[str, object], device: str = "cuda", use_graph: bool = True,
+    def __init__(self, weights: Dict[str, object], device=None, use_graph: bool = True,
                  units: Sequence = UNITS, precision: Optional[str] = None):
         _lib.require_gpu()
         prec = precision or ops.default_precision()
-        self.device, self.use_graph, self.units = device, use_graph, list(units)
+        self.device, self.use_graph, self.units = _lib.resolve_device(device), use_graph, list(units)
+        device = self.device
         self.packed: Dict[str, ops.PackedConv] = {}
         self.affine: Dict[str, tuple] = {}
         self._plans: Dict[tuple, _Plan] = {}

@@ -32,6 +32,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from . import io_pipeline as iop
 from . import jpeg
 
@@ -55,9 +56,7 @@ def _stage_thread(name, fn, q_in, q_out, errors):
         finally:
             if q_out is not None:
                 q_out.put(_END)
-    t = threading.Thread(target=run, name=f"premvos-{name}", daemon=True)
-    t.start()
-    return t
+    return iop.start_thread(run, f"premvos-{name}")        # (selects the creating thread's GPU first)
 
 
 class StreamPipeline:
@@ -68,7 +67,7 @@ class StreamPipeline:
         from .flow import pwc_dc_net
         from .proposal import driver as pd
         from .refinement import driver as rd
-        self.batch, self.out, self.dev = batch, out, "cuda"
+        self.batch, self.out, self.dev = batch, out, _lib.resolve_device()      # (this rank's GPU, indexed: the stage threads use THIS one)
         # Launch lists are issued eagerly here (no HIP-graph capture / replay): four host threads drive the GPU at once, and a
         # capture on one thread while others launch is the one construct this driver avoids (an intermittent hang was seen
         # with it); the ~400 launches of a net cost ~2 ms of host time per call, hidden behind the other threads' work.
@@ -209,8 +208,9 @@ class StreamPipeline:
                 """ONE thread issues the collectives, in chunk order: round k = this rank's k-th chunk (a filler when it has none);
                 the gather of round k is in flight while round k + 1 is computed / packed; the merge rank decodes round k - 1."""
                 try:
-                    # the current device is per host thread and a new thread starts on device 0: select this rank's GPU before
-                    # anything allocates, launches or synchronises here (ranks with LOCAL_RANK > 0 would otherwise pack on GPU 0)
+                    # the current device is per host thread and a new thread starts on device 0: this rank's GPU is selected before
+                    # anything allocates, launches or synchronises here (io_pipeline.start_thread does it for every thread of the
+                    # package; the explicit call keeps the exchange right even when the gather's device is not the creator's)
                     if gather.device.type == "cuda":
                         torch.cuda.set_device(gather.device)
                     x, pending, held = gather.x, {}, None
@@ -242,8 +242,7 @@ class StreamPipeline:
                     errors.append(e)
                     xdead.set()                        # the producer polls this: nobody returns staging blocks any more
             xdead = threading.Event()
-            xthread = threading.Thread(target=exchange_loop, name="premvos-exchange", daemon=True)
-            xthread.start()
+            xthread = iop.start_thread(exchange_loop, "premvos-exchange")
         q_flow, q_g, q_s, q_rg, q_rs = (queue.Queue(maxsize=3) for _ in range(5))
         q_join: "queue.Queue" = queue.Queue(maxsize=3 + self.refine_lanes)
 
@@ -260,8 +259,7 @@ class StreamPipeline:
             finally:
                 for _ in range(self.refine_lanes):   # every consumer of q_join needs its own end marker (a single one left the
                     q_join.put(_END)                 # second refinement thread of a round-2 experiment blocked in get() for ever)
-        joiner = threading.Thread(target=join_props, name="premvos-join", daemon=True)
-        joiner.start()
+        joiner = iop.start_thread(join_props, "premvos-join")
         threads = [_stage_thread("flow", lambda c: self._flow(c, writer), q_flow, None, errors),
                    _stage_thread("prop-general", lambda c: self._proposals(0, c, writer), q_g, q_rg, errors),
                    _stage_thread("prop-specific", lambda c: self._proposals(1, c, writer), q_s, q_rs, errors)]
@@ -480,9 +478,7 @@ class DeviceGather:
         wm = max([hw[1] for hw in sizes.values()] + [8])
         self.hm, self.wm = hm, wm
         self.x = ResultExchange(pipe.batch, hm, wm, self.P, device, pack_bits=pack_bits, unpack_bits=unpack_bits, rle_pool=rle_pool)
-        self.device = torch.device(device)
-        if self.device.type == "cuda" and self.device.index is None:      # taken on the constructing (main) thread: the exchange thread
-            self.device = torch.device("cuda", torch.cuda.current_device())   # selects THIS device, whatever its own default is
+        self.device = _lib.resolve_device(device)    # indexed on the constructing (main) thread: the exchange thread selects THIS device
         self._free: "queue.Queue" = queue.Queue()    # page-locked host buffers (one chunk's prefix each), returned by the writer threads
         self._n_host, self._host_lock = 0, threading.Lock()
         self.rle_overflows = 0                       # chunks whose run boundaries did not fit the pool (encoded from the masks instead)
@@ -667,13 +663,13 @@ def run(root: str, seq_file: str, flow_weights: str, general_weights: str, speci
     n = 0
     if gather and world > 1:
         # one round of the ONE gather per chunk (DeviceGather); every rank runs all rounds, with fillers where it owns nothing
-        dg = DeviceGather(pipe, folders, plans, rank, world, torch.device("cuda"))
+        dg = DeviceGather(pipe, folders, plans, rank, world, pipe.dev)
         n = pipe.run_sequences(folders, plans[rank], gather=dg)
     else:
         n = pipe.run_sequences(folders, plans[rank])
     total = n
     if world > 1:
-        t = torch.tensor([n], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([n], dtype=torch.int64, device=pipe.dev if backend == "nccl" else "cpu")
         dist.all_reduce(t)                                   # also the job's final barrier: every file is on disk after it
         total = int(t.item())
     if rank == 0:

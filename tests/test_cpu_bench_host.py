@@ -68,7 +68,49 @@ def test_canonical_layer_is_the_middle_flow_pointwise_with_residual(bench):
 def test_supplementary_modes_are_an_argument(bench, monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert a.supplementary == "mixed-bf16x3,1080p" and a.gpus == 1 and a.frames == 0
+    assert a.supplementary == "mixed-bf16x3,1080p,1080p-mixed-bf16x3" and a.gpus == 1 and a.frames == 0
     monkeypatch.setattr(sys, "argv", ["bench.py", "--supplementary", "none", "--frames", "40"])
     a = bench.parse()
     assert [m for m in a.supplementary.split(",") if m in ("mixed-bf16x3", "1080p")] == [] and a.frames == 40
+
+
+def test_box_sampler_picks_the_amdsmi_device_by_pci_address_not_by_position(bench, monkeypatch):
+    """amdsmi lists every physical GPU whatever HIP_VISIBLE_DEVICES says; HIP device 0 may be amdsmi's third."""
+    import torch
+    _fake_amdsmi(monkeypatch, [{"current_gfxclk": 2100, "current_socket_power": 900}])
+    smi = sys.modules["amdsmi"]
+    smi.amdsmi_get_processor_handles = lambda: ["a", "b", "c"]
+    smi.amdsmi_get_gpu_device_bdf = lambda h: {"a": "0000:05:00.0", "b": "0000:c1:00.0", "c": "0001:0a:00.0"}[h]
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(pci_domain_id=1, pci_bus_id=0x0A, pci_device_id=0))
+    s = bench.BoxSampler(0)
+    assert s.err is None and s.h == "c" and s.matched_by == "pci 0001:0a:00.0"
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x77, pci_device_id=0))
+    s = bench.BoxSampler(0)
+    assert s.err is not None and "no amdsmi device at PCI 0000:77:00" in s.err and "error" in s.summary()
+
+
+def test_traffic_figure_covers_every_fp32_conv_kernel_the_plans_can_launch():
+    """`roofline.traffic` is read from profiles/rNN_conv_hbm_traffic.json; round 5's file had been produced by a
+    kernel list that lacked the round's new kernel.  Every __global__ of the fp32 conv sources (what premvos_conv2d_f32 dispatches
+    to) must be in tools/pmc_traffic.py's list, and in the list the newest traffic file (round >= 6) was produced with."""
+    import glob
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for fn in glob.glob(os.path.join(root, "premvos_amd", "csrc", "conv_*.hip")):
+        src = open(fn).read()
+        names |= set(re.findall(r"__global__[^;{]*?\bvoid\s+([a-z0-9_]+)\s*\(", src, flags=re.S))
+    conv = {n for n in names if "bf16" not in n and "calibrate" not in n and n not in ("digest_kernel", "split8_kernel")}
+    assert {"conv_igemm_f32_kernel", "conv_pwdma_f32_kernel", "wino4_gemm_kernel", "conv_stream_f32_kernel"} <= conv, conv
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import pmc_traffic
+    finally:
+        sys.path.pop(0)
+    assert conv <= set(pmc_traffic.KERNELS), conv - set(pmc_traffic.KERNELS)
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_conv_hbm_traffic.json")))
+    newest = [f for f in files if int(os.path.basename(f)[1:3]) >= 6][-1:]
+    for f in newest:
+        assert conv <= set(json.load(open(f))["kernels"]), (f, conv - set(json.load(open(f))["kernels"]))
