@@ -176,10 +176,14 @@ def file_to_file(n_frames: int, chunk: int):
     """Secondary measurement, FILE TO FILE: a synthetic 480p JPEG sequence through premvos_amd.stream (one process, this GPU):
     JPEG decode, the four stages, .flo / proposal JSON / combined JSON / refined JSON with COCO-RLE strings on disk -- the
     reference's stage interface.  One cold run (plans are built), then the best of two warm runs."""
+    import importlib.util
     import shutil
     import tempfile
     from PIL import Image
     from premvos_amd import stream, synth
+    spec = importlib.util.spec_from_file_location("time_merge_ingest", os.path.join(ROOT, "tools", "time_merge_ingest.py"))
+    tmi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tmi)
     root = tempfile.mkdtemp(prefix="premvos_f2f_")
     try:
         seq = os.path.join(root, "data", "DAVIS", "JPEGImages", "480p", "clip")
@@ -193,7 +197,9 @@ def file_to_file(n_frames: int, chunk: int):
         torch.save({"state_dict": synth.pwc_state_dict(0)}, os.path.join(wd, "pwc.pth.tar"))
         torch.save(synth.proposal_weights(0), os.path.join(wd, "general.pt"))
         torch.save(synth.proposal_weights(1), os.path.join(wd, "specific.pt"))
-        torch.save(synth.refinement_weights(0), os.path.join(wd, "refine.pt"))
+        # (the refinement net's foreground bias is raised so that the masks are object-like blobs -- with the plain synthetic weights
+        #  every mask is empty and the RLE / JSON side of this leg has nothing to do: tools/time_merge_ingest.py)
+        torch.save(tmi.object_like_refinement_weights(), os.path.join(wd, "refine.pt"))
         out = os.path.join(root, "output", "intermediate")
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
@@ -224,10 +230,6 @@ def file_to_file(n_frames: int, chunk: int):
             # the merge rank of an 8-rank gathered job on THIS GPU (tools/time_merge_ingest.py): the same pipeline object computes rank
             # 0's share while the recorded buffers of 7 other ranks arrive with every round; >= 430 frames/s = 8 x the file-to-file rate
             try:
-                import importlib.util
-                spec = importlib.util.spec_from_file_location("time_merge_ingest", os.path.join(ROOT, "tools", "time_merge_ingest.py"))
-                tmi = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(tmi)
                 job = tmi.build_job(os.path.join(root, "ingest"), 64, 8, weights=False)
                 ingest = tmi.measure(sp, job["clips"], 64, 8, modes=("beside",), reference=False)
                 ingest["measured_by_this_run"] = True

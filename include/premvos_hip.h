@@ -437,6 +437,39 @@ int64_t premvos_rle_counts_to_string_host(const int64_t* counts, int64_t n, char
 int64_t premvos_rle_strings_host(const int32_t* pool, const int32_t* offsets, int32_t n, int64_t hw, char* out, int64_t cap,
                                  int64_t* str_offsets);
 
+/* ---- host-side file writer (no GPU work; premvos_amd/csrc/host_files.hip) -------------------------------------------------
+ * The files of ONE frame from the arrays its results consist of, without the Python interpreter (ctypes releases the interpreter
+ * lock for the call, so N writer threads run at once): what the merge rank of a gathered multi-GPU job does ~430 times per second.
+ * Same bytes as the Python writers of the stage drivers, i.e. as the reference's:
+ *   flo_path      script_pwc_multi.py:16-31 writeFlowFile           (NULL: none -- the last frame of a video has no pair)
+ *   json_path[0]  general proposals   proposal_net/eval.py:93-94 (boxes / scale, clip) + train.py:388-428 (xywh, round, json.dump)
+ *   json_path[1]  specific proposals  (same)
+ *   json_path[2]  combined            combine_general_and_specific.py:33 (general + specific)
+ *   json_path[3]  refined             FewShotSegmentationForwarder.py:137-155: combined + "segmentation" {"size", "counts"} +
+ *                                     "conf_score" (str of the float32); slot i of the frame = rle_offsets[i] .. [i + 1] in rle_pool
+ *                                     (premvos_rle_boundaries_pooled_u8), conf[i]
+ * Any json_path may be NULL (that file is not written).  boxes: [count][4] x0 y0 x1 y1 in RESIZED-image coordinates, probs: [count].
+ * Returns 0, 1 when a directory of some path does not exist (the caller creates it and calls again; files already written are
+ * simply written again) or a negative error. */
+typedef struct premvos_frame_files {
+  const char* flo_path;
+  const float* flow;              /* [h][w][2], flow_row_stride floats between rows (>= 2 w) */
+  int64_t flow_row_stride;
+  int32_t h, w;
+  const float* boxes[2];          /* general, specific */
+  const float* probs[2];
+  int32_t count[2];
+  float scale;                    /* float32 of (newh / h + neww / w) / 2 (eval.py:78) */
+  const char* json_path[4];
+  const float* conf;              /* [count[0] + count[1]] */
+  const int32_t* rle_pool;
+  const int32_t* rle_offsets;     /* [count[0] + count[1] + 1] (a window of the chunk's offsets) */
+} premvos_frame_files;
+int premvos_write_frame_files_host(const premvos_frame_files* f);
+/* Test hook of the number formatting above: n doubles -> one line each, as Python's repr(float) (json.dump) or, as_float32_str != 0,
+ * as numpy's str(float32(value)).  Returns the length written or a negative error. */
+int premvos_format_floats_host(const double* values, int64_t n, int32_t as_float32_str, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL: shares libamdhip64 with the 
 from . import build as _build
 
 _LIB = None
-ABI_VERSION = 17         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
+ABI_VERSION = 18         # premvos_abi_version() of the library this file's SIGNATURES / ConvDesc describe
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ACT_SPLIT8_BF16 = 0x200      # premvos_dwconv3x3_f32: store the resident S8 layout ({hi8, lo8} per group of 8 channels) for premvos_conv_bf16x3_s8_f32
@@ -91,6 +91,13 @@ SIGNATURES = {
 }
 
 
+class FrameFiles(C.Structure):
+    """premvos_frame_files (include/premvos_hip.h): the arguments of premvos_write_frame_files_host."""
+    _fields_ = [("flo_path", C.c_char_p), ("flow", C.c_void_p), ("flow_row_stride", C.c_int64), ("h", C.c_int32), ("w", C.c_int32),
+                ("boxes", C.c_void_p * 2), ("probs", C.c_void_p * 2), ("count", C.c_int32 * 2), ("scale", C.c_float),
+                ("json_path", C.c_char_p * 4), ("conf", C.c_void_p), ("rle_pool", C.c_void_p), ("rle_offsets", C.c_void_p)]
+
+
 class PremvosError(RuntimeError):
     pass
 
@@ -145,6 +152,10 @@ def load():
     lib.premvos_rle_counts_to_string_host.restype = C.c_int64
     lib.premvos_rle_strings_host.argtypes = [_vp, _vp, _i32, C.c_int64, _vp, C.c_int64, _vp]
     lib.premvos_rle_strings_host.restype = C.c_int64
+    lib.premvos_write_frame_files_host.argtypes = [C.POINTER(FrameFiles)]
+    lib.premvos_write_frame_files_host.restype = C.c_int
+    lib.premvos_format_floats_host.argtypes = [_vp, C.c_int64, _i32, _vp, C.c_int64]
+    lib.premvos_format_floats_host.restype = C.c_int
     lib.premvos_rle_workspace_bytes.argtypes = [_i32, _i32, _i32]
     lib.premvos_rle_workspace_bytes.restype = C.c_int64
     lib.premvos_jpeg_workspace_bytes.argtypes = [_vp]

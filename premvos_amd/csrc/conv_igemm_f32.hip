@@ -1184,4 +1184,4 @@ extern "C" int premvos_digest_u64(const void* buf, int64_t pixels, int32_t c, in
   return premvos::check_launch("digest");
 }
 
-extern "C" int premvos_abi_version(void) { return 17; }   // bump with every change of include/premvos_hip.h
+extern "C" int premvos_abi_version(void) { return 18; }   // bump with every change of include/premvos_hip.h

@@ -168,8 +168,12 @@ def clip_boxes(boxes: np.ndarray, shape) -> np.ndarray:
     frame and negative x1 / y1 alone).  Works in place on a C-contiguous input (eval.py:94 relies on that) and returns it."""
     flat = boxes.reshape(-1, 4)                 # a view for contiguous input: the clamps below write through to ``boxes``
     corner, far = flat[:, :2], flat[:, 2:]
-    np.maximum(corner, 0, out=corner)
-    np.minimum(far, np.asarray((shape[1], shape[0]), dtype=flat.dtype), out=far)
+    # (written with comparisons, not np.maximum / np.minimum: which zero maximum(-0.0, 0) returns depends on the SIMD path numpy picks
+    #  for the host, and the C twin of this arithmetic -- csrc/host_files.hip -- must write the same "0.0"; NaN stays NaN)
+    corner[corner <= 0] = 0
+    limit = np.broadcast_to(np.asarray((shape[1], shape[0]), dtype=flat.dtype), far.shape)
+    over = far > limit
+    far[over] = limit[over]
     return flat.reshape(boxes.shape)
 
 

@@ -568,34 +568,67 @@ class DeviceGather:
         return 5 * n - (0 if has_next else 1)
 
     def _finish_frame(self, lease, view, i, seq, name, h, w, scale, write_flow, out, handle):
-        """Writer thread: the five files of one frame from the host copy of its chunk's buffer."""
+        """Writer thread: the five files of one frame from the host copy of its chunk's buffer -- ONE call into libpremvos_hip.so
+        (premvos_write_frame_files_host: number formatting, RLE strings, JSON text, file system calls, all without the interpreter
+        lock, so the writer threads neither queue behind each other nor slow this rank's own launch threads).  The Python writers
+        below (``_finish_frame_py``) produce the same bytes; they serve a chunk whose run boundaries overflowed the pool
+        (``handle``) and PREMVOS_HOST_FILES=py (tests compare the two)."""
+        try:
+            if handle is not None or os.environ.get("PREMVOS_HOST_FILES", "c") == "py":
+                return self._finish_frame_py(view, i, seq, name, h, w, scale, write_flow, out, handle)
+            import ctypes as C
+            f = _lib.FrameFiles()
+            paths = [os.path.join(out, sub, seq, name + ext) for sub, ext in
+                     (("flow", ".flo"), ("general_proposals", ".json"), ("specific_proposals", ".json"), ("combined_proposals", ".json"),
+                      ("refined_proposals", ".json"))]
+            flow = view["flow"]
+            f.flo_path = paths[0].encode() if write_flow else None
+            f.flow, f.flow_row_stride = flow[i].ctypes.data, flow.strides[1] // 4
+            f.h, f.w, f.scale = h, w, float(np.float32(scale))
+            gc, sc = int(view["general_count"][i]), int(view["specific_count"][i])
+            f.boxes[0], f.boxes[1] = view["general_boxes"][i].ctypes.data, view["specific_boxes"][i].ctypes.data
+            f.probs[0], f.probs[1] = view["general_probs"][i].ctypes.data, view["specific_probs"][i].ctypes.data
+            f.count[0], f.count[1] = gc, sc
+            for k in range(4):
+                f.json_path[k] = paths[k + 1].encode()
+            f.conf = view["conf"][i].ctypes.data
+            f.rle_pool = view["rle_pool"].ctypes.data
+            f.rle_offsets = view["rle_offsets"][i * self.P:].ctypes.data
+            lib = _lib.load()
+            rc = lib.premvos_write_frame_files_host(C.byref(f))
+            if rc == 1:                                     # a directory is missing: make them all, once, and write again
+                for fn in paths:
+                    os.makedirs(os.path.dirname(fn), exist_ok=True)
+                rc = lib.premvos_write_frame_files_host(C.byref(f))
+            _lib.check(rc, "write_frame_files")
+        finally:
+            lease.done()
+
+    def _finish_frame_py(self, view, i, seq, name, h, w, scale, write_flow, out, handle):
         from . import rle
         from .mergetrack import encode_masks_finish
         from .proposal.driver import results_json
-        try:
-            if write_flow:
-                _write_flo(os.path.join(out, "flow", seq, name + ".flo"), view["flow"][i, :h, :w])
-            lists = {}
-            for which in ("general", "specific"):
-                lists[which] = results_json(view[which + "_boxes"][i:i + 1], view[which + "_probs"][i:i + 1],
-                                            view[which + "_count"][i:i + 1], scale, (h, w))[0]
-                _dump_json(os.path.join(out, which + "_proposals", seq, name + ".json"), lists[which])
-            both = lists["general"] + lists["specific"]
-            _dump_json(os.path.join(out, "combined_proposals", seq, name + ".json"), both)
-            refined = [dict(p) for p in both]
-            if both:
-                if handle is not None:
-                    segs = encode_masks_finish(handle)
-                else:
-                    first = i * self.P
-                    strings = rle.strings_from_pool(view["rle_pool"], view["rle_offsets"][first:first + len(both) + 1], h * w)
-                    segs = [{"size": [h, w], "counts": c} for c in strings]
-                for q, seg, cv in zip(refined, segs, view["conf"][i]):
-                    q["segmentation"] = seg
-                    q["conf_score"] = str(cv)
-            _dump_json(os.path.join(out, "refined_proposals", seq, name + ".json"), refined)
-        finally:
-            lease.done()
+        if write_flow:
+            _write_flo(os.path.join(out, "flow", seq, name + ".flo"), view["flow"][i, :h, :w])
+        lists = {}
+        for which in ("general", "specific"):
+            lists[which] = results_json(view[which + "_boxes"][i:i + 1], view[which + "_probs"][i:i + 1],
+                                        view[which + "_count"][i:i + 1], scale, (h, w))[0]
+            _dump_json(os.path.join(out, which + "_proposals", seq, name + ".json"), lists[which])
+        both = lists["general"] + lists["specific"]
+        _dump_json(os.path.join(out, "combined_proposals", seq, name + ".json"), both)
+        refined = [dict(p) for p in both]
+        if both:
+            if handle is not None:
+                segs = encode_masks_finish(handle)
+            else:
+                first = i * self.P
+                strings = rle.strings_from_pool(view["rle_pool"], view["rle_offsets"][first:first + len(both) + 1], h * w)
+                segs = [{"size": [h, w], "counts": c} for c in strings]
+            for q, seg, cv in zip(refined, segs, view["conf"][i]):
+                q["segmentation"] = seg
+                q["conf_score"] = str(cv)
+        _dump_json(os.path.join(out, "refined_proposals", seq, name + ".json"), refined)
 
 
 class _Lease:

@@ -143,7 +143,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in premvos_hip.h but not exported"
     assert declared - {"premvos_last_error", "premvos_abi_version", "premvos_refine_output_workspace_bytes",
                        "premvos_conv2d_workspace_bytes", "premvos_crc32c_host", "premvos_rle_workspace_bytes",
-                       "premvos_rle_counts_to_string_host", "premvos_rle_strings_host", "premvos_jpeg_workspace_bytes"} == set(
+                       "premvos_rle_counts_to_string_host", "premvos_rle_strings_host", "premvos_write_frame_files_host", "premvos_format_floats_host", "premvos_jpeg_workspace_bytes"} == set(
         _lib.SIGNATURES)
     assert lib.premvos_abi_version() >= 1
     # argument validation happens before any HIP call, so it is testable without a GPU

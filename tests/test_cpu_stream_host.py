@@ -122,13 +122,15 @@ def _np_twins():
     return {"pack_bits": _np_pack_bits, "unpack_bits": _np_unpack_bits, "rle_pool": _np_rle_pool}, torch
 
 
-@pytest.mark.parametrize("writers,overflow", [(1, False), (3, False), (2, True)])
-def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, monkeypatch, writers, overflow):
+@pytest.mark.parametrize("writers,overflow,host_files", [(1, False, "c"), (3, False, "c"), (2, True, "c"), (2, False, "py")])
+def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, monkeypatch, writers, overflow, host_files):
     """DeviceGather.decode_round (round 6: run boundaries from the producing rank, per-frame host work on N writer threads, buffers
     leased from a pool) against a straightforward per-frame restatement of what a rank's own writers produce: flo_bytes of the flow
     window, results_json of the detections, rle.encode of every mask, str(conf).  ``overflow``: a pool too small for the chunk --
-    the masks themselves are used (the GPU encoder is replaced by its numpy twin here)."""
+    the masks themselves are used (the GPU encoder is replaced by its numpy twin here).  ``host_files``: the interpreter-free C
+    writer (premvos_write_frame_files_host, the default) or its Python twin -- both must produce the restatement's bytes."""
     import json as js
+    monkeypatch.setenv("PREMVOS_HOST_FILES", host_files)
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
     twins, torch = _np_twins()

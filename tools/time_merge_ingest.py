@@ -42,6 +42,18 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def object_like_refinement_weights(shift: float = 7.5):
+    """premvos_amd.synth.refinement_weights(0) with the foreground logit's bias raised: with the plain random weights every mask of
+    the synthetic clip is EMPTY (fg - bg logit = -9 +- 2.6 over a crop: checked with oracle/refinement_oracle.py), so the RLE /
+    string / JSON side of a file-to-file run had nothing to do.  +7.5 gives blob-shaped masks of 4 ... 22 k pixels and 1300 ... 2100
+    run boundaries each -- on the heavy side of a DAVIS object mask.  Used for the file-to-file legs only; bench.py's `value` runs
+    the unmodified synthetic weights (mask content does not change its work)."""
+    from premvos_amd import synth
+    w = synth.refinement_weights(0)
+    w["logits/features/biases"] = w["logits/features/biases"] + torch.tensor([0.0, shift])
+    return w
+
+
 def build_job(root: str, n_frames: int, world: int, h: int = 480, w: int = 854, weights: bool = True) -> dict:
     """A synthetic 480p JPEG clip (quality 95), ``world`` names for it (clip0 = the files, clip1.. = links) and the four weight files."""
     from PIL import Image
@@ -63,7 +75,7 @@ def build_job(root: str, n_frames: int, world: int, h: int = 480, w: int = 854, 
     torch.save({"state_dict": synth.pwc_state_dict(0)}, os.path.join(wd, "pwc.pth.tar"))
     torch.save(synth.proposal_weights(0), os.path.join(wd, "general.pt"))
     torch.save(synth.proposal_weights(1), os.path.join(wd, "specific.pt"))
-    torch.save(synth.refinement_weights(0), os.path.join(wd, "refine.pt"))
+    torch.save(object_like_refinement_weights(), os.path.join(wd, "refine.pt"))
     return {"clips": clips,
             "weights": [os.path.join(wd, n) for n in ("pwc.pth.tar", "general.pt", "specific.pt", "refine.pt")]}
 
