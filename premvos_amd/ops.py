@@ -97,24 +97,25 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None,
     is stored as bfloat16 high parts (+ low parts w - float(hi)) and k is padded to 32."""
     prec = _lib.PRECISIONS[precision]
     device = _lib.resolve_device(device)
-    w = weight.detach().to(torch.float32).cpu()
+    # (round 6: the raw tensor is uploaded ONCE and folded / permuted / padded on the device -- the same IEEE operations as on the
+    #  host, so the packed bits do not change; packing the ~360 convs of the three nets on the host cost 3.5 s of a rank's cold start)
+    w = weight.detach().to(device=device, dtype=torch.float32)
     cout, cin, kh, kw = w.shape
     if scale is not None:
-        w = w * scale.detach().to(torch.float32).cpu().view(-1, 1, 1, 1)
+        w = w * scale.detach().to(device=device, dtype=torch.float32).view(-1, 1, 1, 1)
     cin_pad, cout_pad = _r(cin, 4), _r(cout, 32)
     k = kh * kw * cin_pad
     k_pad = _r(k, 16 if prec == _lib.PREC_F32 else 32)
-    p = torch.zeros((cout_pad, kh * kw, cin_pad), dtype=torch.float32)
+    p = torch.zeros((cout_pad, kh * kw, cin_pad), dtype=torch.float32, device=device)
     p[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
-    full = torch.zeros((cout_pad, k_pad), dtype=torch.float32)
+    full = torch.zeros((cout_pad, k_pad), dtype=torch.float32, device=device)
     full[:, :k] = p.reshape(cout_pad, k)
     b = None
     if bias is not None:
-        b = torch.zeros(cout_pad, dtype=torch.float32)
-        b[:cout] = bias.detach().to(torch.float32).cpu()
-        b = b.to(device)
+        b = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+        b[:cout] = bias.detach().to(device=device, dtype=torch.float32)
     if prec == _lib.PREC_F32:
-        pk = PackedConv(full.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
+        pk = PackedConv(full, b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad)
         if (kh, kw) == (3, 3) and cout % 4 == 0 and cin >= WINO_MIN_CIN and wino_enabled():
             pk.wgt_wino = pack_winograd(w, cin_pad, cout_pad, device)
             if cin >= (WINO4_MIN_C if wino4_min_c is None else wino4_min_c) and cout >= WINO4_MIN_COUT and wino4_enabled():
@@ -122,8 +123,8 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], device=None,
         return pk
     hi = full.to(torch.bfloat16)
     if prec != _lib.PREC_BF16X3:
-        return PackedConv(hi.to(device).contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec, None)
-    both = torch.stack([hi, (full - hi.float()).to(torch.bfloat16)]).to(device).contiguous()
+        return PackedConv(hi.contiguous(), b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec, None)
+    both = torch.stack([hi, (full - hi.float()).to(torch.bfloat16)]).contiguous()
     return PackedConv(both[0], b, cin, cout, kh, kw, cin_pad, k_pad, cout_pad, 0, prec, both[1])
 
 
