@@ -35,3 +35,14 @@ for lvl, c, h, w in LEVELS:
     t2 = timed(lambda: (ops.warp(f2, flow, 1.25, wb), ops.corr(f1, wb, dst, 4, 0.1, True)))
     print(f"level {lvl}: C={c:3d} {h:3d}x{w:3d} x{B}  corr {t:8.1f} us  {byt / t / 1e6:7.2f} TB/s | warp+corr fused {tw:8.1f} us "
           f"({(byt + npix * 8) / tw / 1e6:5.2f} TB/s) vs warp, corr {t2:8.1f} us", flush=True)
+
+# the backward bilinear warp on its own (PWCDCNet.warp, PWCNet.py:140-176; flow_ops.hip::warp_kernel): reads the C channels of up to
+# four neighbours per pixel (unique: the feature map once) + the 2-channel flow, writes C channels -- algorithmic bytes = 2 C + 2 floats
+print()
+for lvl, c, h, w in LEVELS[1:]:
+    f2 = ops.NHWC(torch.randn((B, h, w, c), device="cuda"))
+    flow = ops.NHWC((torch.randn((B, h, w, 4), device="cuda") * 2.0).contiguous(), c=2)
+    wb = ops.NHWC.alloc(B, h, w, c)
+    byt = B * h * w * 4 * (2 * c + 2)
+    t = timed(lambda: ops.warp(f2, flow, 1.25, wb), reps=50)
+    print(f"warp level {lvl}: C={c:3d} {h:3d}x{w:3d} x{B}  {t:7.1f} us  {byt / t / 1e6:6.2f} TB/s algorithmic ({byt / 1e6:.1f} MB)", flush=True)
