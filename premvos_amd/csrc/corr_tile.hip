@@ -24,41 +24,48 @@
 // ~1100 register moves and odd-width LDS reads per chunk: 3x slower)
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "warp_math.h"
 
+
+
 namespace {
 
-constexpr int T_H = 8, T_W = 32, MD = 4, D = 2 * MD + 1;
-constexpr int HALO_H = T_H + 2 * MD, HALO_W = T_W + 2 * MD;
-constexpr int NT = 512;             // two threads per pixel of the tile
+constexpr int MD = 4, D = 2 * MD + 1;
 constexpr int D0 = 5;               // displacement rows of a pixel's first thread (dy = -4..0); the second has D - D0 = 4
-constexpr int CCH = 16;            // channels per LDS chunk
-constexpr int PSTR = CCH + 4;      // padded pixel stride (floats)
-constexpr int LDS_FLOATS = HALO_H * HALO_W * PSTR;   // 12 800 floats = 51 200 B; two 8-wave workgroups per CU (128 VGPRs)
 
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // 16 bytes at 4-byte alignment
 
-template <bool WARP>
-__global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restrict__ f1, int f1_ps,
-                                                          const float* __restrict__ f2, int f2_ps,
-                                                          const float* __restrict__ flow, int flow_ps, float fscale,
-                                                          float* __restrict__ out, int out_ps, int h, int w, int c,
-                                                          float slope, int copy_f1, int tiles_x, int tiles_y) {
+// T_H x T_W pixel tile, two threads per pixel, CCH channels per LDS chunk, OCC = waves per SIMD the register allocation must allow.
+// PREFETCH (round 6): the global loads of chunk k + 1 are issued BEFORE chunk k is multiplied (the staging registers are dead once
+// their values are in LDS; only the f1 registers double) -- the committed kernel requested a chunk, waited, multiplied, and so paid
+// the memory latency of every chunk pass in full: its load phase ALONE took 101 of 150 us at the 128x224 level (section 7.3).
+template <bool WARP, int T_H, int T_W, int CCH, int OCC, bool PREFETCH>
+__global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const float* __restrict__ f1, int f1_ps,
+                                                                        const float* __restrict__ f2, int f2_ps,
+                                                                        const float* __restrict__ flow, int flow_ps, float fscale,
+                                                                        float* __restrict__ out, int out_ps, int h, int w, int c,
+                                                                        float slope, int copy_f1, int tiles_x, int tiles_y) {
+  constexpr int NPIX = T_H * T_W, NT = 2 * NPIX;
+  constexpr int HALO_H = T_H + 2 * MD, HALO_W = T_W + 2 * MD;
+  constexpr int PSTR = CCH + 4;      // padded pixel stride (floats): 5 (9) x 16 B, odd -> ds_read_b128 of consecutive pixels is conflict-free
+  constexpr int NA = 44, NB = D * D - NA, PB = 40;
+  constexpr int LDS_HALO = HALO_H * HALO_W * PSTR, LDS_OUT = NPIX * NA;
+  constexpr int LDS_FLOATS = LDS_HALO > LDS_OUT ? LDS_HALO : LDS_OUT;
+  constexpr int Q = CCH / 4;
+  constexpr int NUNITS = HALO_H * HALO_W * Q, NSTG = (NUNITS + NT - 1) / NT;
+  static_assert(NPIX % 64 == 0, "a wave is one half of 64 pixels");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tid = threadIdx.x;
-  const int pid = tid & 255, half = tid >> 8;           // pixel of the tile, which half of the displacement rows
-  const int tx = pid & 31, ty = pid >> 5;
+  const int pid = tid % NPIX, half = tid / NPIX;        // pixel of the tile, which half of the displacement rows
+  const int tx = pid % T_W, ty = pid / T_W;
   const int dy0 = half ? D0 : 0;                        // this thread's displacement rows are [dy0, dy0 + (half ? D - D0 : D0))
   // Tile order: the dispatcher places workgroup b on XCD b % 8 (private 4 MB L2 each).  Give every XCD a contiguous run of
   // the (image, tile row, tile column) raster, so that the tiles sharing f2 halo rows / columns read them through ONE L2
   // (with the plain order 55 % of the f2 requests missed L2: 2.2x the algorithmic fetch).  Pure speed, any order is correct.
-  int tile;
-  {
-    const int nwg = gridDim.x, id = blockIdx.x;
-    const int xcd = id & 7, local = id >> 3, q8 = nwg >> 3, r8 = nwg & 7;
-    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;
-  }
+  const int tile = premvos::xcd_contiguous(blockIdx.x, gridDim.x);
   const int n = tile / (tiles_x * tiles_y), trem = tile - n * (tiles_x * tiles_y);
   const int x0 = (trem % tiles_x) * T_W, y0 = (trem / tiles_x) * T_H;
   const int x = x0 + tx, y = y0 + ty;
@@ -70,54 +77,55 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < D0 * D; ++i) acc[i] = 0.f;
 
-  for (int k0 = 0; k0 < c; k0 += CCH) {
-    if (k0) __syncthreads();       // every wave is done reading the previous chunk
-    // ---- stage the f2 halo tile: 640 pixels x 4 float4 = 10 per thread, all loads issued before the first LDS write
-    constexpr int NSTG = HALO_H * HALO_W * (CCH / 4) / NT;
-    static_assert(NSTG * NT == HALO_H * HALO_W * (CCH / 4), "staging loop must divide evenly");
-    // (out-of-range lanes load from a clamped address and are zeroed when written to LDS: a select on a register with
-    //  a load in flight would force the wave to wait for that load before issuing the next one)
-    float4 v[NSTG];
-    auto halo = [&](int j, int& slot, long& pix, int& ch, int& gy, int& gx) {
-      const int i = tid + j * NT;
-      const int px = i >> 2, q = i & 3;
-      const int hy = px / HALO_W, hx = px - hy * HALO_W;
-      gy = y0 + hy - MD, gx = x0 + hx - MD;
-      ch = k0 + q * 4;
-      slot = px * PSTR + q * 4;
-      const bool ok = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w && ch < c;
-      pix = img + (long)(ok ? gy : 0) * w + (ok ? gx : 0);
-      if (!ok) ch = 0;
-      return ok;
-    };
+  // ---- staging of the f2 halo tile: HALO_H x HALO_W pixels x Q float4 per chunk, NSTG per thread.  Out-of-range lanes load from a
+  // clamped address and are zeroed when written to LDS: a select on a register with a load in flight would force the wave to wait
+  // for that load before issuing the next one.
+  auto halo = [&](int j, int k0, int& slot, long& pix, int& ch, int& gy, int& gx) {
+    int i = tid + j * NT;
+    const bool in = NUNITS % NT == 0 || i < NUNITS;
+    i = in ? i : 0;
+    const int px = i / Q, q = i - px * Q;
+    const int hy = px / HALO_W, hx = px - hy * HALO_W;
+    gy = y0 + hy - MD, gx = x0 + hx - MD;
+    ch = k0 + q * 4;
+    slot = in ? px * PSTR + q * 4 : -1;
+    const bool ok = in && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w && ch < c;
+    pix = img + (long)(ok ? gy : 0) * w + (ok ? gx : 0);
+    if (!ok) ch = 0;
+    return ok;
+  };
+  float4 v[NSTG];
+  float4 a[Q], an[Q];
+  auto request = [&](int k0, float4 (&av)[Q]) {          // all global loads of one chunk, nothing waits
 #pragma unroll
     for (int j = 0; j < NSTG; ++j) {
       int slot, ch, gy, gx;
       long pix;
-      halo(j, slot, pix, ch, gy, gx);
+      halo(j, k0, slot, pix, ch, gy, gx);
       if constexpr (WARP) {
         const float* fl = flow + pix * flow_ps;
         v[j] = premvos::warp_sample4(f2 + img * f2_ps + ch, f2_ps, fl[0] * fscale, fl[1] * fscale, gx, gy, h, w);
       } else {
-#ifdef CORR_DBG_NO_LOAD
-        v[j] = make_float4((float)pix, (float)ch, 0.f, 1.f);
-#else
         v[j] = *reinterpret_cast<const float4*>(f2 + pix * f2_ps + ch);
-#endif
       }
     }
-    float4 a[CCH / 4];
 #pragma unroll
-    for (int q = 0; q < CCH / 4; ++q) a[q] = *reinterpret_cast<const float4*>(a_ptr + (valid && k0 + q * 4 < c ? k0 + q * 4 : 0));
+    for (int q = 0; q < Q; ++q) av[q] = *reinterpret_cast<const float4*>(a_ptr + (valid && k0 + q * 4 < c ? k0 + q * 4 : 0));
+  };
+
+  if (PREFETCH) request(0, a);
+  for (int k0 = 0; k0 < c; k0 += CCH) {
+    if (k0) __syncthreads();       // every wave is done reading the previous chunk
+    if (!PREFETCH) request(k0, a);
 #pragma unroll
     for (int j = 0; j < NSTG; ++j) {
       int slot, ch, gy, gx;
       long pix;
-      const bool ok = halo(j, slot, pix, ch, gy, gx);
-      *reinterpret_cast<float4*>(&lds[slot]) = ok ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = halo(j, k0, slot, pix, ch, gy, gx);
+      if (slot >= 0) *reinterpret_cast<float4*>(&lds[slot]) = ok ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int q = 0; q < CCH / 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
       const bool ok = valid && k0 + q * 4 < c;
       if (!ok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       // torch.cat((corr, c1, ...)) (PWCNet.py:213): c1 goes out straight from the registers (the window starts 81 floats
@@ -125,11 +133,9 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
       if (copy_f1 && ok && half == (q & 1)) *reinterpret_cast<f4u*>(out + (img + (long)y * w + x) * out_ps + D * D + k0 + q * 4) = f4u{a[q].x, a[q].y, a[q].z, a[q].w};
     }
     __syncthreads();
-#ifdef CORR_DBG_NO_COMPUTE
-    acc[0] += lds[pid] + a[0].x;
-    continue;
-#endif
-    // ---- 81 displacements x 16 channels ------------------------------------------------------
+    const bool more = k0 + CCH < c;
+    if (PREFETCH && more) request(k0 + CCH, an);         // in flight under the multiplications below
+    // ---- 81 displacements x CCH channels ------------------------------------------------------
     const float* base = &lds[((ty + dy0) * HALO_W + tx) * PSTR];
     // per (displacement row, 4-channel group): 9 independent LDS reads in flight, then 9 independent FMA chains
     auto rows = [&](auto nrows_) {
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
 #pragma unroll
       for (int dy = 0; dy < nrows; ++dy)
 #pragma unroll
-        for (int q = 0; q < CCH / 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
           float4 b[D];
 #pragma unroll
           for (int dx = 0; dx < D; ++dx) b[dx] = *reinterpret_cast<const float4*>(base + (dy * HALO_W + dx) * PSTR + q * 4);
@@ -150,11 +156,15 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
             s = fmaf(a[q].w, b[dx].w, s);
             acc[dy * D + dx] = s;
           }
-          __builtin_amdgcn_sched_barrier(0);        // one round of reads ahead at most: 128 VGPRs have no room for more
+          __builtin_amdgcn_sched_barrier(0);        // one round of reads ahead at most
         }
     };
     if (half == 0) rows(std::integral_constant<int, D0>{});          // wave-uniform: a wave is one half of 64 pixels
     else rows(std::integral_constant<int, D - D0>{});
+    if (PREFETCH && more) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) a[q] = an[q];
+    }
   }
 
   // ---- mean over C (sum / (float)sumelems, corr_cuda_kernel.cu:124-126), LeakyReLU, coalesced runs ----------------
@@ -165,15 +175,14 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
   const int wave = tid >> 6, lane = tid & 63;
   const bool wide = ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) && (out_ps & 3) == 0;
   auto mean_act = [&](float sum) {
-    const float v = pow2 ? sum * rc : sum / fc;
-    return v < 0.f ? v * slope : v;
+    const float v_ = pow2 ? sum * rc : sum / fc;
+    return v_ < 0.f ? v_ * slope : v_;
   };
   // The 81 sums of a pixel leave through LDS so that the pixel's run goes out in 16-byte pieces (the run starts 16-byte
   // aligned when `wide`): pass A = elements [0,44) = 11 float4 per pixel, all from the pixel's thread 0, LDS row pitch 44 (the
   // rows tile LDS linearly: conflict-free b128 writes and reads); pass B = elements [44,81) = 9 float4 + 1 float, row pitch 40:
   // element 44 (dy = 0, dx = +4) from thread 0, elements [45,81) = the 36 sums of thread 1.
-  constexpr int NA = 44, NB = D * D - NA, PB = 40;
-  static_assert(NA % 4 == 0 && NB == 37 && D0 * D == NA + 1 && 256 * NA <= LDS_FLOATS && 256 * PB <= LDS_FLOATS, "output staging layout");
+  static_assert(NA % 4 == 0 && NB == 37 && D0 * D == NA + 1 && NPIX * PB <= LDS_FLOATS, "output staging layout");
   auto stage_a = [&]() {
     if (half == 0) {
 #pragma unroll
@@ -190,14 +199,14 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
     }
   };
   auto pix_of = [&](int p, bool& ok) {
-    const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+    const int yy = y0 + p / T_W, xx = x0 + p % T_W;
     ok = yy < h && xx < w;
     return (img + (long)yy * w + xx) * out_ps;
   };
   auto flush = [&](int e0, int n4, int pitch, int tail) {     // n4 float4 (+ `tail` single floats) per pixel row of LDS
     __syncthreads();
     if (wide) {
-      for (int u = tid; u < 256 * n4; u += NT) {
+      for (int u = tid; u < NPIX * n4; u += NT) {
         const int p = u / n4, j = u - p * n4;
         bool ok;
         const long o = pix_of(p, ok);
@@ -210,22 +219,13 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
       }
     } else {                                          // unaligned destination: one wave per pixel run, 4-byte stores
       const int ne = 4 * n4 + tail;
-      for (int p = wave; p < T_H * T_W; p += NT / 64) {
+      for (int p = wave; p < NPIX; p += NT / 64) {
         bool ok;
         const long o = pix_of(p, ok);
         if (ok && lane < ne) out[o + e0 + lane] = lds[p * pitch + lane];
       }
     }
   };
-#ifdef CORR_DBG_NO_OUTPUT
-  {
-    float t = 0.f;
-#pragma unroll
-    for (int e = 0; e < D0 * D; ++e) t += acc[e];
-    if (t == 1234.5f) out[0] = t;
-    return;
-  }
-#endif
   __syncthreads();                                   // f2 tile no longer needed
   stage_a();
   flush(0, NA / 4, NA, 0);
@@ -234,20 +234,54 @@ __global__ __launch_bounds__(NT, 4) void corr81_tile_kernel(const float* __restr
   flush(NA, NB / 4, PB, 1);
 }
 
+template <bool WARP, int T_H, int T_W, int CCH, int OCC, bool PREFETCH>
+int launch_variant(const float* f1, int f1_ps, const float* f2, int f2_ps, const float* flow, int flow_ps, float fscale, float* out,
+                   int out_ps, int n, int h, int w, int c, float slope, int copy_f1, hipStream_t s) {
+  const int tx = premvos::cdiv(w, T_W), ty = premvos::cdiv(h, T_H);
+  hipLaunchKernelGGL((corr81_tile_kernel<WARP, T_H, T_W, CCH, OCC, PREFETCH>), dim3(tx * ty * n), dim3(2 * T_H * T_W), 0, s, f1, f1_ps, f2,
+                     f2_ps, flow, flow_ps, fscale, out, out_ps, h, w, c, slope, copy_f1, tx, ty);
+  return premvos::check_launch("corr81_tile");
+}
+
 }  // namespace
 
 namespace premvos {
+// PREMVOS_CORR_VARIANT (developer A/B, tools/time_corr.py): 0 = the round-2 form (8 x 32 tile, 16-channel chunks, four waves per
+// SIMD, load - wait - multiply); the others differ in tile, chunk depth, occupancy and whether the next chunk's loads are in flight
+// under the multiplications.  Every variant adds the same products in the same order: bit-identical outputs.
 int corr81_tile(const float* f1, int f1_ps, const float* f2, int f2_ps, const float* flow, int flow_ps, float fscale,
                 float* out, int out_ps, int n, int h, int w, int c, float slope, int copy_f1, hipStream_t s) {
-  const int tx = cdiv(w, T_W), ty = cdiv(h, T_H);
-  const dim3 grid(tx * ty * n);
-  if (flow != nullptr)
-    hipLaunchKernelGGL(corr81_tile_kernel<true>, grid, dim3(NT), 0, s, f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out,
-                       out_ps, h, w, c, slope, copy_f1, tx, ty);
-  else
-    hipLaunchKernelGGL(corr81_tile_kernel<false>, grid, dim3(NT), 0, s, f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out,
-                       out_ps, h, w, c, slope, copy_f1, tx, ty);
-  return check_launch("corr81_tile");
+  static const int env_variant = [] {
+    const char* e = getenv("PREMVOS_CORR_VARIANT");
+    return e ? atoi(e) : -1;
+  }();
+  // Default (profiles/r06_corr_variants.txt, 16 pairs): whole 128-byte pixel rows per chunk on an 8 x 16 tile (variant 5: 256-thread
+  // workgroups, two per CU) where the map has <= 32 channels -- the 128 x 224 level: 152 -> 126 us, its rows used to be requested as
+  // two 64-byte halves 20 ... 30 us apart -- or too few 8 x 32 tiles to give every CU two (the 32 x 56 / 16 x 28 levels: 40 -> 35 us);
+  // the 64-channel 64 x 112 level stays on the round-2 form (56 vs 64 us).  The fused warp form keeps the round-2 tile (its
+  // bilinear gathers need the registers).
+  const long tiles_8x32 = (long)cdiv(w, 32) * cdiv(h, 8) * n;
+  const int rule = flow == nullptr && (c <= 32 || tiles_8x32 < 512) ? 5 : 0;
+  const int variant = env_variant >= 0 ? env_variant : rule;
+#define PV_CORR(TH, TW, CC, OC, PF)                                                                                                   \
+  return flow != nullptr ? launch_variant<true, TH, TW, CC, OC, PF>(f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out, out_ps, n, h, w, c, \
+                                                                     slope, copy_f1, s)                                                 \
+                         : launch_variant<false, TH, TW, CC, OC, PF>(f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out, out_ps, n, h, w, c, \
+                                                                      slope, copy_f1, s)
+  switch (variant) {
+    case 1: PV_CORR(8, 32, 16, 2, true);
+    case 2: PV_CORR(8, 16, 16, 4, false);
+    case 3: PV_CORR(8, 16, 16, 3, true);
+    case 4: PV_CORR(4, 32, 16, 3, true);
+    case 5: PV_CORR(8, 16, 32, 3, false);
+    case 6: PV_CORR(8, 16, 32, 2, true);
+    case 7: PV_CORR(16, 16, 16, 4, false);
+    case 8: PV_CORR(16, 16, 16, 2, true);
+    case 9: PV_CORR(8, 32, 32, 2, false);
+    case 10: PV_CORR(8, 16, 16, 2, true);
+    default: PV_CORR(8, 32, 16, 4, false);
+  }
+#undef PV_CORR
 }
 }  // namespace premvos
 

@@ -55,6 +55,10 @@ for prec in fp32 mixed-bf16x3; do
   grep '^{' "$OUT/${TAG}_bench_1080p_$prec.log" | tail -1 > "$OUT/${TAG}_bench_1080p_$prec.json"
 done
 python tools/time_merge_loop.py --out "$OUT/${TAG}_merge_loop.json" > /dev/null 2>&1
+# 8. round 6: the merge rank of a gathered 8-rank job on this one GPU (recorded buffers of 7 ranks replayed beside the real driver), in
+#    the shipped form and in round 5's; where a rank's cold start goes
+python tools/time_merge_ingest.py --frames 128 --legacy --out "$OUT/${TAG}_merge_ingest.json" > "$OUT/${TAG}_merge_ingest.log" 2>&1
+python tools/dev/cold_start_profile.py > "$OUT/${TAG}_cold_start_profile.txt" 2>&1
 python bench.py > "$OUT/${TAG}_bench_fp32.log" 2>&1
 grep '^{' "$OUT/${TAG}_bench_fp32.log" | tail -1 > "$OUT/${TAG}_bench_fp32.json"
 # keep only the small summaries (the traces are tens of MB)

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from premvos_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+torch.manual_seed(0)
 LEVELS = [(6, 196, 8, 14), (5, 128, 16, 28), (4, 96, 32, 56), (3, 64, 64, 112), (2, 32, 128, 224)]
 
 
@@ -30,10 +31,11 @@ for lvl, c, h, w in LEVELS:
     npix = B * h * w
     byt = npix * 4 * (2 * c + 81 + c)
     t = timed(lambda: ops.corr(f1, f2, dst, 4, 0.1, True))
+    dig = int(out.buf.view(torch.int32).to(torch.int64).sum().item())      # (same seed, same bits: variants must agree)
     tw = timed(lambda: ops.warp_corr(f1, f2, flow, 1.25, dst, 4, 0.1, True))
     wb = ops.NHWC.alloc(B, h, w, c)
     t2 = timed(lambda: (ops.warp(f2, flow, 1.25, wb), ops.corr(f1, wb, dst, 4, 0.1, True)))
-    print(f"level {lvl}: C={c:3d} {h:3d}x{w:3d} x{B}  corr {t:8.1f} us  {byt / t / 1e6:7.2f} TB/s | warp+corr fused {tw:8.1f} us "
+    print(f"level {lvl}: C={c:3d} {h:3d}x{w:3d} x{B}  corr {t:8.1f} us  {byt / t / 1e6:7.2f} TB/s  digest {dig & 0xffffffffffff:012x} | warp+corr fused {tw:8.1f} us "
           f"({(byt + npix * 8) / tw / 1e6:5.2f} TB/s) vs warp, corr {t2:8.1f} us", flush=True)
 
 # the backward bilinear warp on its own (PWCDCNet.warp, PWCNet.py:140-176; flow_ops.hip::warp_kernel): reads the C channels of up to
