@@ -42,13 +42,16 @@ struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };     // 16 
 // PREFETCH (round 6): the global loads of chunk k + 1 are issued BEFORE chunk k is multiplied (the staging registers are dead once
 // their values are in LDS; only the f1 registers double) -- the committed kernel requested a chunk, waited, multiplied, and so paid
 // the memory latency of every chunk pass in full: its load phase ALONE took 101 of 150 us at the 128x224 level (section 7.3).
-template <bool WARP, int T_H, int T_W, int CCH, int OCC, bool PREFETCH>
-__global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const float* __restrict__ f1, int f1_ps,
+// PPT = 2 (round 6 experiment): a thread owns TWO vertically adjacent pixels -- displacement row dy of pixel (x, y + 1) multiplies the
+// same f2 row as row dy + 1 of pixel (x, y), so a thread reads nrows + 1 halo rows from LDS for 2 x nrows rows of sums (0.6x the LDS
+// reads per FMA; twice the accumulators).
+template <bool WARP, int T_H, int T_W, int CCH, int OCC, bool PREFETCH, int PPT = 1>
+__global__ __launch_bounds__(2 * T_H * T_W / PPT, OCC) void corr81_tile_kernel(const float* __restrict__ f1, int f1_ps,
                                                                         const float* __restrict__ f2, int f2_ps,
                                                                         const float* __restrict__ flow, int flow_ps, float fscale,
                                                                         float* __restrict__ out, int out_ps, int h, int w, int c,
                                                                         float slope, int copy_f1, int tiles_x, int tiles_y) {
-  constexpr int NPIX = T_H * T_W, NT = 2 * NPIX;
+  constexpr int NPIX = T_H * T_W, NTH = NPIX / PPT, NT = 2 * NTH;
   constexpr int HALO_H = T_H + 2 * MD, HALO_W = T_W + 2 * MD;
   constexpr int PSTR = CCH + 4;      // padded pixel stride (floats): 5 (9) x 16 B, odd -> ds_read_b128 of consecutive pixels is conflict-free
   constexpr int NA = 44, NB = D * D - NA, PB = 40;
@@ -56,11 +59,11 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
   constexpr int LDS_FLOATS = LDS_HALO > LDS_OUT ? LDS_HALO : LDS_OUT;
   constexpr int Q = CCH / 4;
   constexpr int NUNITS = HALO_H * HALO_W * Q, NSTG = (NUNITS + NT - 1) / NT;
-  static_assert(NPIX % 64 == 0, "a wave is one half of 64 pixels");
+  static_assert(NTH % 64 == 0 && T_H % PPT == 0, "a wave is one half of 64 pixels (or pixel pairs)");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tid = threadIdx.x;
-  const int pid = tid % NPIX, half = tid / NPIX;        // pixel of the tile, which half of the displacement rows
-  const int tx = pid % T_W, ty = pid / T_W;
+  const int tix = tid % NTH, half = tid / NTH;          // pixel (pair) of the tile, which half of the displacement rows
+  const int tx = tix % T_W, ty = (tix / T_W) * PPT;     // (the thread's first pixel; its second one is the pixel below)
   const int dy0 = half ? D0 : 0;                        // this thread's displacement rows are [dy0, dy0 + (half ? D - D0 : D0))
   // Tile order: the dispatcher places workgroup b on XCD b % 8 (private 4 MB L2 each).  Give every XCD a contiguous run of
   // the (image, tile row, tile column) raster, so that the tiles sharing f2 halo rows / columns read them through ONE L2
@@ -68,14 +71,24 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
   const int tile = premvos::xcd_contiguous(blockIdx.x, gridDim.x);
   const int n = tile / (tiles_x * tiles_y), trem = tile - n * (tiles_x * tiles_y);
   const int x0 = (trem % tiles_x) * T_W, y0 = (trem / tiles_x) * T_H;
-  const int x = x0 + tx, y = y0 + ty;
-  const bool valid = x < w && y < h;
+  const int x = x0 + tx;
   const long img = (long)n * h * w;
-  const float* a_ptr = f1 + (img + (long)(valid ? y : 0) * w + (valid ? x : 0)) * f1_ps;
-
-  float acc[D0 * D];                                    // (half 1 uses the first (D - D0) * D of them)
+  bool valid[PPT];
+  const float* a_ptr[PPT];
+  int pidx[PPT];                                        // index of the pixel in the tile's row-major order (output staging)
 #pragma unroll
-  for (int i = 0; i < D0 * D; ++i) acc[i] = 0.f;
+  for (int p = 0; p < PPT; ++p) {
+    const int y = y0 + ty + p;
+    valid[p] = x < w && y < h;
+    a_ptr[p] = f1 + (img + (long)(valid[p] ? y : 0) * w + (valid[p] ? x : 0)) * f1_ps;
+    pidx[p] = (ty + p) * T_W + tx;
+  }
+
+  float acc[PPT][D0 * D];                               // (half 1 uses the first (D - D0) * D of them)
+#pragma unroll
+  for (int p = 0; p < PPT; ++p)
+#pragma unroll
+    for (int i = 0; i < D0 * D; ++i) acc[p][i] = 0.f;
 
   // ---- staging of the f2 halo tile: HALO_H x HALO_W pixels x Q float4 per chunk, NSTG per thread.  Out-of-range lanes load from a
   // clamped address and are zeroed when written to LDS: a select on a register with a load in flight would force the wave to wait
@@ -95,8 +108,8 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
     return ok;
   };
   float4 v[NSTG];
-  float4 a[Q], an[Q];
-  auto request = [&](int k0, float4 (&av)[Q]) {          // all global loads of one chunk, nothing waits
+  float4 a[PPT][Q], an[PPT][Q];
+  auto request = [&](int k0, float4 (&av)[PPT][Q]) {     // all global loads of one chunk, nothing waits
 #pragma unroll
     for (int j = 0; j < NSTG; ++j) {
       int slot, ch, gy, gx;
@@ -110,7 +123,9 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
       }
     }
 #pragma unroll
-    for (int q = 0; q < Q; ++q) av[q] = *reinterpret_cast<const float4*>(a_ptr + (valid && k0 + q * 4 < c ? k0 + q * 4 : 0));
+    for (int p = 0; p < PPT; ++p)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) av[p][q] = *reinterpret_cast<const float4*>(a_ptr[p] + (valid[p] && k0 + q * 4 < c ? k0 + q * 4 : 0));
   };
 
   if (PREFETCH) request(0, a);
@@ -125,36 +140,44 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
       if (slot >= 0) *reinterpret_cast<float4*>(&lds[slot]) = ok ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const bool ok = valid && k0 + q * 4 < c;
-      if (!ok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      // torch.cat((corr, c1, ...)) (PWCNet.py:213): c1 goes out straight from the registers (the window starts 81 floats
-      // into the pixel, so only 4-byte alignment is known)
-      if (copy_f1 && ok && half == (q & 1)) *reinterpret_cast<f4u*>(out + (img + (long)y * w + x) * out_ps + D * D + k0 + q * 4) = f4u{a[q].x, a[q].y, a[q].z, a[q].w};
-    }
+    for (int p = 0; p < PPT; ++p)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const bool ok = valid[p] && k0 + q * 4 < c;
+        if (!ok) a[p][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // torch.cat((corr, c1, ...)) (PWCNet.py:213): c1 goes out straight from the registers (the window starts 81 floats
+        // into the pixel, so only 4-byte alignment is known)
+        if (copy_f1 && ok && half == (q & 1))
+          *reinterpret_cast<f4u*>(out + (img + (long)(y0 + ty + p) * w + x) * out_ps + D * D + k0 + q * 4) = f4u{a[p][q].x, a[p][q].y, a[p][q].z, a[p][q].w};
+      }
     __syncthreads();
     const bool more = k0 + CCH < c;
     if (PREFETCH && more) request(k0 + CCH, an);         // in flight under the multiplications below
     // ---- 81 displacements x CCH channels ------------------------------------------------------
-    const float* base = &lds[((ty + dy0) * HALO_W + tx) * PSTR];
+    const float* base = &lds[((ty + dy0) * HALO_W + tx) * PSTR];       // (ty = the thread's FIRST pixel)
     // per (displacement row, 4-channel group): 9 independent LDS reads in flight, then 9 independent FMA chains
     auto rows = [&](auto nrows_) {
       constexpr int nrows = decltype(nrows_)::value;
 #pragma unroll
-      for (int dy = 0; dy < nrows; ++dy)
+      for (int rr = 0; rr < nrows + PPT - 1; ++rr)       // halo row rr below the first pixel's first displacement row
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
           float4 b[D];
 #pragma unroll
-          for (int dx = 0; dx < D; ++dx) b[dx] = *reinterpret_cast<const float4*>(base + (dy * HALO_W + dx) * PSTR + q * 4);
+          for (int dx = 0; dx < D; ++dx) b[dx] = *reinterpret_cast<const float4*>(base + (rr * HALO_W + dx) * PSTR + q * 4);
 #pragma unroll
-          for (int dx = 0; dx < D; ++dx) {
-            float s = acc[dy * D + dx];
-            s = fmaf(a[q].x, b[dx].x, s);
-            s = fmaf(a[q].y, b[dx].y, s);
-            s = fmaf(a[q].z, b[dx].z, s);
-            s = fmaf(a[q].w, b[dx].w, s);
-            acc[dy * D + dx] = s;
+          for (int p = 0; p < PPT; ++p) {
+            const int dy = rr - p;                       // pixel p sits p rows lower: the same halo row is its displacement row rr - p
+            if (dy < 0 || dy >= nrows) continue;
+#pragma unroll
+            for (int dx = 0; dx < D; ++dx) {
+              float s = acc[p][dy * D + dx];
+              s = fmaf(a[p][q].x, b[dx].x, s);
+              s = fmaf(a[p][q].y, b[dx].y, s);
+              s = fmaf(a[p][q].z, b[dx].z, s);
+              s = fmaf(a[p][q].w, b[dx].w, s);
+              acc[p][dy * D + dx] = s;
+            }
           }
           __builtin_amdgcn_sched_barrier(0);        // one round of reads ahead at most
         }
@@ -163,7 +186,9 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
     else rows(std::integral_constant<int, D - D0>{});
     if (PREFETCH && more) {
 #pragma unroll
-      for (int q = 0; q < Q; ++q) a[q] = an[q];
+      for (int p = 0; p < PPT; ++p)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) a[p][q] = an[p][q];
     }
   }
 
@@ -186,16 +211,22 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
   auto stage_a = [&]() {
     if (half == 0) {
 #pragma unroll
-      for (int j = 0; j < NA / 4; ++j)
-        *reinterpret_cast<float4*>(&lds[pid * NA + 4 * j]) = make_float4(mean_act(acc[4 * j]), mean_act(acc[4 * j + 1]), mean_act(acc[4 * j + 2]), mean_act(acc[4 * j + 3]));
+      for (int p = 0; p < PPT; ++p)
+#pragma unroll
+        for (int j = 0; j < NA / 4; ++j)
+          *reinterpret_cast<float4*>(&lds[pidx[p] * NA + 4 * j]) =
+              make_float4(mean_act(acc[p][4 * j]), mean_act(acc[p][4 * j + 1]), mean_act(acc[p][4 * j + 2]), mean_act(acc[p][4 * j + 3]));
     }
   };
   auto stage_b = [&]() {
-    if (half == 0) {
-      lds[pid * PB] = mean_act(acc[NA]);
-    } else {
 #pragma unroll
-      for (int e = 0; e < (D - D0) * D; ++e) lds[pid * PB + 1 + e] = mean_act(acc[e]);
+    for (int p = 0; p < PPT; ++p) {
+      if (half == 0) {
+        lds[pidx[p] * PB] = mean_act(acc[p][NA]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < (D - D0) * D; ++e) lds[pidx[p] * PB + 1 + e] = mean_act(acc[p][e]);
+      }
     }
   };
   auto pix_of = [&](int p, bool& ok) {
@@ -213,9 +244,12 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
         if (ok) *reinterpret_cast<float4*>(out + o + e0 + 4 * j) = *reinterpret_cast<const float4*>(&lds[p * pitch + 4 * j]);
       }
       if (tail && half == 0) {
-        bool ok;
-        const long o = pix_of(pid, ok);
-        if (ok) out[o + e0 + 4 * n4] = lds[pid * pitch + 4 * n4];
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+          bool ok;
+          const long o = pix_of(pidx[p], ok);
+          if (ok) out[o + e0 + 4 * n4] = lds[pidx[p] * pitch + 4 * n4];
+        }
       }
     } else {                                          // unaligned destination: one wave per pixel run, 4-byte stores
       const int ne = 4 * n4 + tail;
@@ -234,11 +268,11 @@ __global__ __launch_bounds__(2 * T_H * T_W, OCC) void corr81_tile_kernel(const f
   flush(NA, NB / 4, PB, 1);
 }
 
-template <bool WARP, int T_H, int T_W, int CCH, int OCC, bool PREFETCH>
+template <bool WARP, int T_H, int T_W, int CCH, int OCC, bool PREFETCH, int PPT = 1>
 int launch_variant(const float* f1, int f1_ps, const float* f2, int f2_ps, const float* flow, int flow_ps, float fscale, float* out,
                    int out_ps, int n, int h, int w, int c, float slope, int copy_f1, hipStream_t s) {
   const int tx = premvos::cdiv(w, T_W), ty = premvos::cdiv(h, T_H);
-  hipLaunchKernelGGL((corr81_tile_kernel<WARP, T_H, T_W, CCH, OCC, PREFETCH>), dim3(tx * ty * n), dim3(2 * T_H * T_W), 0, s, f1, f1_ps, f2,
+  hipLaunchKernelGGL((corr81_tile_kernel<WARP, T_H, T_W, CCH, OCC, PREFETCH, PPT>), dim3(tx * ty * n), dim3(2 * T_H * T_W / PPT), 0, s, f1, f1_ps, f2,
                      f2_ps, flow, flow_ps, fscale, out, out_ps, h, w, c, slope, copy_f1, tx, ty);
   return premvos::check_launch("corr81_tile");
 }
@@ -261,7 +295,9 @@ int corr81_tile(const float* f1, int f1_ps, const float* f2, int f2_ps, const fl
   // the 64-channel 64 x 112 level stays on the round-2 form (56 vs 64 us).  The fused warp form keeps the round-2 tile (its
   // bilinear gathers need the registers).
   const long tiles_8x32 = (long)cdiv(w, 32) * cdiv(h, 8) * n;
-  const int rule = flow == nullptr && (c <= 32 || tiles_8x32 < 512) ? 5 : 0;
+  // ... and there two pixels per thread (variant 11: 0.6x the LDS reads per FMA) are worth 55 -> 51 us; on small maps that form starves
+  // (half the threads per tile) and at C = 32 the level is bound by its memory phases, not by LDS (135 vs 134 us).
+  const int rule = flow != nullptr ? 0 : (c <= 32 || tiles_8x32 < 512) ? 5 : c <= 64 ? 11 : 0;
   const int variant = env_variant >= 0 ? env_variant : rule;
 #define PV_CORR(TH, TW, CC, OC, PF)                                                                                                   \
   return flow != nullptr ? launch_variant<true, TH, TW, CC, OC, PF>(f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out, out_ps, n, h, w, c, \
@@ -279,6 +315,10 @@ int corr81_tile(const float* f1, int f1_ps, const float* f2, int f2_ps, const fl
     case 8: PV_CORR(16, 16, 16, 2, true);
     case 9: PV_CORR(8, 32, 32, 2, false);
     case 10: PV_CORR(8, 16, 16, 2, true);
+    case 11: return launch_variant<false, 8, 32, 16, 2, false, 2>(f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out, out_ps, n, h, w, c, slope, copy_f1, s);
+    case 12: return launch_variant<false, 8, 32, 16, 2, true, 2>(f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out, out_ps, n, h, w, c, slope, copy_f1, s);
+    case 13: return launch_variant<false, 16, 16, 16, 2, false, 2>(f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out, out_ps, n, h, w, c, slope, copy_f1, s);
+    case 14: return launch_variant<false, 8, 32, 16, 3, false, 2>(f1, f1_ps, f2, f2_ps, flow, flow_ps, fscale, out, out_ps, n, h, w, c, slope, copy_f1, s);
     default: PV_CORR(8, 32, 16, 4, false);
   }
 #undef PV_CORR
