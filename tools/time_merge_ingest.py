@@ -342,6 +342,8 @@ def main() -> int:
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("PREMVOS_STREAM_BATCH", "8")))
     ap.add_argument("--legacy", action="store_true", help="also replay the round-5 form of the merge side")
+    ap.add_argument("--modes", default="alone,beside")
+    ap.add_argument("--repeat", type=int, default=1, help="measure the round-6 form this many times (same pipeline object)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "merge_ingest.json"))
     a = ap.parse_args()
     from premvos_amd import stream
@@ -350,7 +352,9 @@ def main() -> int:
     try:
         job = build_job(root, a.frames, a.world)
         sp = stream.StreamPipeline(*job["weights"], batch=a.chunk, out=os.path.join(root, "output"))
-        rep = {"now": measure(sp, job["clips"], a.frames, a.world)}
+        rep = {"now": measure(sp, job["clips"], a.frames, a.world, modes=tuple(a.modes.split(",")))}
+        for i in range(1, a.repeat):
+            rep[f"now_{i + 1}"] = measure(sp, job["clips"], a.frames, a.world, modes=tuple(a.modes.split(",")), reference=False)
         if a.legacy:
             rep["round5_form"] = measure(sp, job["clips"], a.frames, a.world, legacy=True, reference=False)
         rep["host"] = {"cpu_count": os.cpu_count(), "local_world_size_assumed": int(os.environ["LOCAL_WORLD_SIZE"])}
