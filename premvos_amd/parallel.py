@@ -59,20 +59,43 @@ def max_shard(n_items: int, world: int) -> int:
     return (max(n_items, 0) + world - 1) // world
 
 
-def balance_videos(frame_counts: List[int], world: int) -> List[List[int]]:
+def balance_videos(frame_counts: List[int], world: int, capacity: Optional[List[float]] = None) -> List[List[int]]:
     """Whole videos per rank, longest video first onto the least loaded rank (ties: lower rank, lower index) -- the same
-    granularity as the reference's hand-edited list slices (``shard_videos``), but balanced by frame count.  Deterministic;
-    returns the video indices of every rank in ascending order."""
+    granularity as the reference's hand-edited list slices (``shard_videos``), but balanced by frame count.  ``capacity``: relative
+    speed of every rank (default all 1): a rank's load counts as frames / capacity, a rank of capacity 0 gets nothing.
+    Deterministic; returns the video indices of every rank in ascending order."""
+    cap = [1.0] * world if capacity is None else list(capacity)
+    live = [r for r in range(world) if cap[r] > 0]
+    if not live:
+        raise ValueError("no rank with a positive capacity")
     load, out = [0] * world, [[] for _ in range(world)]
     for v in sorted(range(len(frame_counts)), key=lambda i: (-frame_counts[i], i)):
-        r = min(range(world), key=lambda k: (load[k], k))
+        r = min(live, key=lambda k: ((load[k] + frame_counts[v]) / cap[k], k)) if capacity is not None else \
+            min(range(world), key=lambda k: (load[k], k))
         load[r] += frame_counts[v]
         out[r].append(v)
     return [sorted(x) for x in out]
 
 
+def weighted_ranges(n_items: int, capacity: List[float]) -> List[Tuple[int, int]]:
+    """[start, end) of ``n_items`` for every rank, sizes proportional to ``capacity`` (largest-remainder rounding, ties to the lower
+    rank): the contiguous split of ``shard_range`` for ranks of unequal speed."""
+    total = float(sum(capacity))
+    if total <= 0:
+        raise ValueError("no rank with a positive capacity")
+    exact = [max(n_items, 0) * c / total for c in capacity]
+    size = [int(e) for e in exact]
+    for r in sorted(range(len(capacity)), key=lambda k: (-(exact[k] - size[k]), k))[:max(n_items, 0) - sum(size)]:
+        size[r] += 1
+    out, start = [], 0
+    for sz in size:
+        out.append((start, start + sz))
+        start += sz
+    return out
+
+
 def plan_shards(frame_counts: List[int], world: int, rank: int, chunk: int,
-                scheme: str = "balanced") -> List[Tuple[int, int, int]]:
+                scheme: str = "balanced", merge_share: float = 1.0, merge_rank: int = 0) -> List[Tuple[int, int, int]]:
     """The work of ``rank``: a list of (video index, first frame, end frame).
 
     * at least ``world`` videos: whole videos per rank (``scheme`` = "balanced": by frame count; "contiguous": the reference's
@@ -83,28 +106,41 @@ def plan_shards(frame_counts: List[int], world: int, rank: int, chunk: int,
       Frame pair t = (t, t+1) belongs to the rank that owns frame t, so a rank whose range ends before the video does also
       READS frame ``end`` (second image of its last pair, script_pwc_multi.py:100-102); it writes nothing for it.
       Successive videos start their split at a rotated rank, so the ranks holding one chunk more are not always the first ones.
+    * ``merge_share`` < 1 (round 6): ``merge_rank`` -- the rank that also turns every rank's gathered results into files
+      (stream.DeviceGather) -- is planned as a rank of that relative speed: it computes its own chunks ~4 % slower beside the other
+      ranks' copies and writer traffic (profiles/r06_merge_ingest.json), and a statically balanced job is as fast as its slowest rank.
+      0 = the merge rank computes nothing.  Which frames a rank owns never changes what is computed for a frame.
     """
     if world <= 0 or not (0 <= rank < world):
         raise ValueError("bad world/rank")
     if chunk <= 0:
         raise ValueError("chunk must be positive")
+    if not (0.0 <= merge_share <= 1.0) or not (0 <= merge_rank < world):
+        raise ValueError("merge_share must lie in [0, 1], merge_rank in [0, world)")
+    if world == 1:
+        merge_share = 1.0
+    capacity = None if merge_share == 1.0 else [merge_share if r == merge_rank else 1.0 for r in range(world)]
     nv = len(frame_counts)
-    if nv >= world:
+    live = world if capacity is None or merge_share > 0 else world - 1
+    if nv >= live:
         if scheme == "contiguous":
-            s, e = shard_range(nv, world, rank)
+            s, e = shard_range(nv, world, rank) if capacity is None else weighted_ranges(nv, capacity)[rank]
             mine = list(range(s, e))
         elif scheme == "balanced":
-            mine = balance_videos(frame_counts, world)[rank]
+            mine = balance_videos(frame_counts, world, capacity)[rank]
         else:
             raise ValueError(f"unknown sharding scheme {scheme!r}")
         return [(v, 0, frame_counts[v]) for v in mine if frame_counts[v] > 0]
     out, rot = [], 0
     for v, n in enumerate(frame_counts):
         n_chunks = -(-n // chunk)
-        cs, ce = shard_range(n_chunks, world, (rank + rot) % world)
+        if capacity is None:
+            cs, ce = shard_range(n_chunks, world, (rank + rot) % world)
+            rot = (rot + world - n_chunks % world) % world
+        else:                      # (no rotation: the weighted split already decides who holds the odd chunk)
+            cs, ce = weighted_ranges(n_chunks, capacity)[rank]
         if ce > cs:
             out.append((v, cs * chunk, min(ce * chunk, n)))
-        rot = (rot + world - n_chunks % world) % world
     return out
 
 

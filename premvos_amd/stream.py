@@ -671,7 +671,8 @@ def _self_launch(gpus: int, argv: List[str]) -> int:
 
 
 def run(root: str, seq_file: str, flow_weights: str, general_weights: str, specific_weights: str, refinement_weights: str,
-        batch: int = 8, out: str = "output/intermediate", shard: str = "balanced", gather: bool = False) -> int:
+        batch: int = 8, out: str = "output/intermediate", shard: str = "balanced", gather: bool = False,
+        merge_share: float = 1.0) -> int:
     """One rank of the job (the only one when WORLD_SIZE is unset): device = LOCAL_RANK, work = its shards of the videos of
     ``seq_file`` (premvos_amd.parallel.plan_shards: whole videos when there are at least as many as ranks -- the reference's
     granularity, DAVISFewShotSegmentationDataset.py:130-150, merge.py:66-67,126-128 -- else chunk-aligned frame ranges with the
@@ -697,7 +698,9 @@ def run(root: str, seq_file: str, flow_weights: str, general_weights: str, speci
     with open(seq_file) as f:
         folders = [ln.rstrip() for ln in f if ln.rstrip()]
     counts = [len(glob.glob(os.path.join(v, "*"))) for v in folders]
-    plans = [plan_shards(counts, world, r, batch, shard) for r in range(world)]
+    # (--gather: rank 0 also writes every rank's files; --merge-share < 1 plans it as a slower rank, 0 = it computes nothing)
+    share = merge_share if gather and world > 1 else 1.0
+    plans = [plan_shards(counts, world, r, batch, shard, merge_share=share) for r in range(world)]
     pipe = StreamPipeline(flow_weights, general_weights, specific_weights, refinement_weights, batch, out)
     n = 0
     if gather and world > 1:
@@ -717,7 +720,7 @@ def run(root: str, seq_file: str, flow_weights: str, general_weights: str, speci
         # lives NEXT TO the stage tree (<out>/../premvos_amd_manifest.json), never inside `out` -- the tree the byte-identity
         # promise (and tests/test_gpu_plumbing.py::_same_tree) covers is `out` = output/intermediate, what ReID / MergeTrack read
         _dump_json(os.path.join(os.path.dirname(out.rstrip("/")) or ".", "premvos_amd_manifest.json"),
-                   {"frames": total, "ranks": world, "chunk": batch, "sharding": shard,
+                   {"frames": total, "ranks": world, "chunk": batch, "sharding": shard, "merge_share": share,
                     "shards": [[[folders[v], a, b] for v, a, b in p] for p in plans], "conv_configurations": ops.tune_info()})
     if world > 1:
         dist.barrier()
@@ -740,14 +743,17 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--shard", default="balanced", choices=["balanced", "contiguous"],
                     help="whole-video assignment when there are at least --gpus videos: by frame count, or the reference's slices")
     ap.add_argument("--gather", action="store_true",
-                    help="hand every rank's files to rank 0 (one gather per shard item) instead of writing them per rank")
+                    help="hand every rank's results to rank 0 (ONE gather of one packed buffer per round of chunks); rank 0 writes every file")
+    ap.add_argument("--merge-share", type=float, default=float(os.environ.get("PREMVOS_MERGE_SHARE", "1.0")),
+                    help="with --gather: relative speed rank 0 is planned with (it also writes every rank's files: ~0.95 measured at 8 "
+                         "ranks); 0 = rank 0 computes nothing, 1 = equal shares (default)")
     a = ap.parse_args(argv)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return _self_launch(a.gpus, argv)
     if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} was started with WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     n = run(a.root, a.seq_file, a.flow_weights, a.general_weights, a.specific_weights, a.refinement_weights, a.batch,
-            shard=a.shard, gather=a.gather)
+            shard=a.shard, gather=a.gather, merge_share=a.merge_share)
     if int(os.environ.get("RANK", "0")) == 0:
         print("frames:", n)
     return 0

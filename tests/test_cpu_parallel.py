@@ -198,6 +198,43 @@ def test_result_exchange_run_boundaries_window_overflow_and_strings():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # the product's sharding (premvos_amd.stream.run -> parallel.plan_shards + stream.iter_chunks)
+def test_plan_shards_with_a_slower_or_idle_merge_rank():
+    """``merge_share`` (round 6): the rank that also writes every rank's gathered files is planned as a slower rank.  Whatever the
+    share, every frame is owned exactly once, cuts stay on chunk boundaries (same chunks as the one-rank run), and share 1 is the
+    old plan."""
+    import random
+    rng = random.Random(3)
+    for _ in range(60):
+        world, chunk = rng.randint(2, 9), rng.choice([2, 8, 16])
+        counts = [rng.randint(0, 200) for _ in range(rng.randint(1, 14))]
+        for share in (1.0, 0.9, 0.5, 0.0):
+            for scheme in ("balanced", "contiguous"):
+                plans = [P.plan_shards(counts, world, r, chunk, scheme, merge_share=share) for r in range(world)]
+                if share == 1.0:
+                    assert plans == [P.plan_shards(counts, world, r, chunk, scheme) for r in range(world)]
+                owned = {}
+                for r, pl in enumerate(plans):
+                    for v, a, b in pl:
+                        assert 0 <= a < b <= counts[v] and a % chunk == 0 and (b % chunk == 0 or b == counts[v])
+                        for t in range(a, b):
+                            assert (v, t) not in owned
+                            owned[(v, t)] = r
+                assert len(owned) == sum(counts)
+                if share == 0.0:
+                    assert plans[0] == []
+    # one long video over 8 ranks: 125 chunks, rank 0 planned at 0.9 -> 14 chunks where the others hold 15 or 16
+    plans = [P.plan_shards([1000], 8, r, 8, merge_share=0.9) for r in range(8)]
+    sizes = [-(-(b - a) // 8) for pl in plans for _, a, b in pl]
+    assert sizes[0] == 14 and sorted(sizes[1:]) == [15, 16, 16, 16, 16, 16, 16] and sum(sizes) == 125
+    # whole videos: the merge rank's frames / share is what gets balanced
+    plans = [P.plan_shards([100] * 15 + [50], 4, r, 8, merge_share=0.5) for r in range(4)]
+    frames = [sum(b - a for _, a, b in pl) for pl in plans]
+    assert frames[0] <= 0.6 * min(frames[1:]) and sum(frames) == 1550
+    assert P.weighted_ranges(10, [0.9, 1, 1, 1]) == [(0, 2), (2, 5), (5, 8), (8, 10)] and P.weighted_ranges(0, [1, 1]) == [(0, 0), (0, 0)]
+    with pytest.raises(ValueError):
+        P.plan_shards([10], 2, 0, 8, merge_share=1.5)
+
+
 def test_plan_shards_whole_videos_and_chunk_aligned_ranges():
     # at least as many videos as ranks: whole videos, balanced by frame count (or the reference's contiguous slices)
     counts = [70, 50, 30, 90, 20]

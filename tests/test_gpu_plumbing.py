@@ -288,10 +288,12 @@ def test_two_ranks_write_the_one_rank_tree_whole_videos(tmp_path):
 
 def test_two_ranks_write_the_one_rank_tree_frame_ranges(tmp_path):
     """Fewer videos than ranks: ONE 7-frame video in chunks of 2 -> rank 0 owns frames [0,4) and reads frame 4 as the second
-    image of its last flow pair, rank 1 owns [4,7).  Same bytes as the 1-rank run, with per-rank writers and with --gather
-    (every file handed to rank 0 in one padded gather per shard item)."""
+    image of its last flow pair, rank 1 owns [4,7).  Same bytes as the 1-rank run, with per-rank writers, with --gather (every
+    rank's results handed to rank 0 in one gather per round of chunks) and with a merge rank that computes nothing itself
+    (--merge-share 0: rank 0 only takes part in the gathers and writes rank 1's files)."""
     roots = []
-    for tag, gpus, extra in (("one", 1, ()), ("two", 2, ()), ("gathered", 2, ("--gather",))):
+    for tag, gpus, extra in (("one", 1, ()), ("two", 2, ()), ("gathered", 2, ("--gather",)),
+                             ("merge_only", 2, ("--gather", "--merge-share", "0"))):
         root = tmp_path / tag
         root.mkdir()
         _make_tree(root, t=7)
@@ -301,6 +303,8 @@ def test_two_ranks_write_the_one_rank_tree_frame_ranges(tmp_path):
         _same_tree(roots[0] / "intermediate", other / "intermediate", 6 + 4 * 7)
     m = json.load(open(roots[1] / "premvos_amd_manifest.json"))
     assert sorted((a, b) for p in m["shards"] for _, a, b in p) == [(0, 4), (4, 7)]
+    m = json.load(open(roots[3] / "premvos_amd_manifest.json"))
+    assert m["merge_share"] == 0.0 and m["shards"][0] == [] and [(a, b) for _, a, b in m["shards"][1]] == [(0, 7)]
 
 
 def test_binary_side_car_holds_what_the_json_holds(tmp_path):
