@@ -52,6 +52,14 @@ def test_bench_line_through_the_distributed_path():
     pr = d["per_rank"]
     assert len(pr["ms_per_step"]) == 1 and pr["rank_skew_ms_per_step"] == 0.0 and pr["exchange_wait_ms_per_step"][0] >= 0.0
     assert pr["cold_start_s"][0] > 0 and d["cold_start_s"] == pr["cold_start_s"][0]
+    # round 6: the whole launch priced against the same peak (every kernel of a frame, the timed region's own wall time), and a cold
+    # start that no longer counts the synthesis of weights / frames on the host
+    gf = d["config"]["gflop_per_frame"]
+    assert abs(r["whole_step_frac"] - 2 * gf * 1e9 / (r["whole_step_ms_per_launch"] * 1e-3) / 1e12 / 157.3) < 2e-3
+    assert 0.05 < r["whole_step_frac"] < r["frac"] + 0.05 and abs(r["non_conv_ms_per_launch"] - (r["whole_step_ms_per_launch"] - r["conv_ms_per_step"])) < 1e-2
+    cs = d["cold_start"]
+    assert abs(cs["build_pipeline_s"] + cs["first_launch_s"] - d["cold_start_s"]) < 0.03 and cs["synthetic_inputs_s"] > 0
+    assert d["cold_start_s"] < 30 and d["box"].get("device_matched_by", "pci").startswith(("pci", "position"))
 
 
 def test_bench_launches_its_own_ranks():
