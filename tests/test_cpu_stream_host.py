@@ -122,13 +122,16 @@ def _np_twins():
     return {"pack_bits": _np_pack_bits, "unpack_bits": _np_unpack_bits, "rle_pool": _np_rle_pool}, torch
 
 
-@pytest.mark.parametrize("writers,overflow,host_files", [(1, False, "c"), (3, False, "c"), (2, True, "c"), (2, False, "py")])
-def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, monkeypatch, writers, overflow, host_files):
+@pytest.mark.parametrize("writers,overflow,host_files,bigger", [(1, False, "c", False), (3, False, "c", False), (2, True, "c", False),
+                                                                  (2, False, "py", False), (2, False, "c", True), (1, True, "py", True)])
+def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, monkeypatch, writers, overflow, host_files, bigger):
     """DeviceGather.decode_round (round 6: run boundaries from the producing rank, per-frame host work on N writer threads, buffers
     leased from a pool) against a straightforward per-frame restatement of what a rank's own writers produce: flo_bytes of the flow
     window, results_json of the detections, rle.encode of every mask, str(conf).  ``overflow``: a pool too small for the chunk --
     the masks themselves are used (the GPU encoder is replaced by its numpy twin here).  ``host_files``: the interpreter-free C
-    writer (premvos_write_frame_files_host, the default) or its Python twin -- both must produce the restatement's bytes."""
+    writer (premvos_write_frame_files_host, the default) or its Python twin -- both must produce the restatement's bytes.
+    ``bigger``: another rank owns a video of LARGER frames, so the job's buffers are sized for those and this video's frames are
+    the top-left window of every block (flow rows with a wider stride, run boundaries over the h x w window of a larger mask)."""
     import json as js
     monkeypatch.setenv("PREMVOS_HOST_FILES", host_files)
     import sys
@@ -156,8 +159,14 @@ def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, mon
                 pos[i, :len(r)] = r
             return pos, np.array([len(r) for r in rows], np.int32), m.shape[1], m.shape[2]
         monkeypatch.setattr(mergetrack, "encode_masks_begin", begin)
-    dg = stream.DeviceGather(pipe, [str(d) + "/"], [[(0, 0, T)]], 0, 1, "cpu", **twins)
-    assert dg.rounds == 2 and dg.chunks[0][1][2] is False
+    folders, plans = [str(d) + "/"], [[(0, 0, T)]]
+    if bigger:
+        d2 = tmp_path / "JPEGImages" / "wide"
+        d2.mkdir()
+        Image.fromarray(np.zeros((h + 5, w + 9, 3), np.uint8)).save(d2 / "00000.png")
+        folders, plans = folders + [str(d2) + "/"], plans + [[(1, 0, 1)]]
+    dg = stream.DeviceGather(pipe, folders, plans, 0, len(plans), "cpu", **twins)
+    assert dg.rounds == 2 and dg.chunks[0][1][2] is False and (dg.hm, dg.wm) == ((h + 5, w + 9) if bigger else (h, w))
     rng = np.random.default_rng(3)
     out = str(tmp_path / "out")
     expect = {}
@@ -166,7 +175,7 @@ def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, mon
             n = len(names)
             r = dg.staging()
             r["hw"] = (h, w)
-            r["flow"][:n] = torch.from_numpy(rng.standard_normal((n, h, w, 2)).astype(np.float32))
+            r["flow"][:n, :h, :w] = torch.from_numpy(rng.standard_normal((n, h, w, 2)).astype(np.float32))
             gc, sc = rng.integers(0, 4, n), rng.integers(0, 4, n)
             r["general_count"][:n], r["specific_count"][:n] = torch.from_numpy(gc.astype(np.int32)), torch.from_numpy(sc.astype(np.int32))
             for key in ("general", "specific"):
@@ -174,10 +183,22 @@ def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, mon
                 r[key + "_boxes"][:n] = torch.from_numpy(np.concatenate([xy, xy + rng.uniform(1, 60, (n, 20, 2)).astype(np.float32)], -1))
                 r[key + "_probs"][:n] = torch.from_numpy(rng.uniform(0.5, 1, (n, 20)).astype(np.float32))
             r["conf"][:n] = torch.from_numpy(rng.uniform(-1, 1, (n, dg.P)).astype(np.float32))
-            r["masks"][:n] = torch.from_numpy((rng.random((n, dg.P, h, w)) > 0.55).astype(np.uint8))
+            r["masks"][:n, :, :h, :w] = torch.from_numpy((rng.random((n, dg.P, h, w)) > 0.55).astype(np.uint8))
+            if bigger:                                 # (what lies outside the frame's window must not reach any file)
+                r["masks"][:, :, h:, :] = 1
+                r["masks"][:, :, :, w:] = 1
+                r["flow"][:, h:] = 7.0
+                r["flow"][:, :, w:] = 7.0
             slot = dg.x.exchange_async(r)
             dg.x.wait(slot)
-            assert dg.decode_round(k, dg.x.gathered_slot(slot), out, wr) == 5 * n - (0 if has_next else 1)
+            bufs = dg.x.gathered_slot(slot) * len(plans)              # (rank 1 owns one chunk in round 0: it gets the same bytes)
+            files = dg.decode_round(k, bufs, out if not bigger else str(tmp_path / "out_all"), wr)
+            if bigger:                                 # round 0 also decoded rank 1's (one-frame, last-of-video) chunk: 4 files
+                assert files == 5 * n - (0 if has_next else 1) + (4 if k == 0 else 0)
+                out_dir = str(tmp_path / "out_all")
+            else:
+                assert files == 5 * n - (0 if has_next else 1)
+                out_dir = out
             # the restatement (what the producing rank's own writers would have written)
             nh, nw = custom_resize_shape(h, w)
             scale = (nh * 1.0 / h + nw * 1.0 / w) / 2
@@ -185,26 +206,27 @@ def test_merge_rank_turns_gathered_buffers_into_the_per_rank_files(tmp_path, mon
             s = results_json(r["specific_boxes"][:n].numpy(), r["specific_probs"][:n].numpy(), sc, scale, (h, w))
             for i, name in enumerate(names):
                 if has_next or i < n - 1:
-                    expect[f"flow/{seq}/{name}.flo"] = flo_bytes(r["flow"][i].numpy())
+                    expect[f"flow/{seq}/{name}.flo"] = flo_bytes(r["flow"][i, :h, :w].numpy())
                 both = g[i] + s[i]
                 expect[f"general_proposals/{seq}/{name}.json"] = js.dumps(g[i]).encode()
                 expect[f"specific_proposals/{seq}/{name}.json"] = js.dumps(s[i]).encode()
                 expect[f"combined_proposals/{seq}/{name}.json"] = js.dumps(both).encode()
                 ref = [dict(p) for p in both]
                 for j, q in enumerate(ref):
-                    q["segmentation"] = rle.encode(r["masks"][i, j].numpy())
+                    q["segmentation"] = rle.encode(r["masks"][i, j, :h, :w].numpy())
                     q["conf_score"] = str(r["conf"][i, j].numpy())
                 expect[f"refined_proposals/{seq}/{name}.json"] = js.dumps(ref).encode()
-    assert dg.rle_overflows == (2 if overflow else 0)
+    assert dg.rle_overflows == ((3 if bigger else 2) if overflow else 0)      # (bigger: round 0 also decodes the other rank's chunk)
     got = {}
-    for root, _, files in os.walk(out):
+    for root, _, files in os.walk(out_dir):
         for f in files:
             fn = os.path.join(root, f)
-            got[os.path.relpath(fn, out)] = open(fn, "rb").read()
+            if "/wide/" not in fn:                     # (the other rank's video: not what this test restates)
+                got[os.path.relpath(fn, out_dir)] = open(fn, "rb").read()
     assert sorted(got) == sorted(expect) and len(got) == 5 * T - 1
     for key in expect:
         assert got[key] == expect[key], key
-    assert dg._free.qsize() == dg._n_host <= 4           # every leased host buffer came back
+    assert dg._free.qsize() == dg._n_host <= 6           # every leased host buffer came back
 
 
 def test_writer_threads_run_every_call_count_their_time_and_report_the_first_error():
