@@ -118,3 +118,32 @@ def test_bad_arguments_are_errors_not_crashes(tmp_path):
     assert lib.premvos_write_frame_files_host(C.byref(f)) < 0
     f.flo_path = None
     assert lib.premvos_write_frame_files_host(C.byref(f)) == 0             # nothing to write is fine
+
+
+def test_box_arithmetic_matches_numpy_on_hostile_values(tmp_path):
+    """eval.py:93-94 + train.py:388-428 on values a real net can emit and a synthetic one will: huge, tiny, negative, exactly on the
+    clip limits, half-way cases of the rounding, infinities and NaNs -- the C twin's float32 arithmetic and number formatting against
+    numpy + json (NaN / Infinity are what json.dumps writes for them, and what the reference would have written)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    h, w, scale = 480, 854, (749 / 480 + 1333 / 854) / 2
+    pool, off, conf = np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.float32)
+    specials = np.array([0.0, -0.0, 0.05, 0.15, 0.25, 0.35, 1e-7, -1e-7, 1e9, -1e9, 3.4e38, -3.4e38, np.inf, -np.inf, np.nan, 854.0 * scale,
+                         480.0 * scale, 854.04 * scale, 0.049999, 1234.5678, 16777216.0], np.float32)
+    for rep in range(40):
+        boxes = np.zeros((2, 20, 4), np.float32)
+        boxes[0] = (rng.standard_normal((20, 4)) * 10.0 ** rng.integers(-3, 6, (20, 4))).astype(np.float32)
+        boxes[1] = rng.choice(specials, (20, 4))
+        probs = np.concatenate([rng.uniform(0, 1, (1, 20)), rng.choice([0.005, 0.015, 0.125, 0.995, 1.0, 0.0, 0.5, np.nan], (1, 20))]).astype(np.float32)
+        f = _lib.FrameFiles()
+        f.h, f.w, f.scale = h, w, float(np.float32(scale))
+        for k in range(2):
+            f.boxes[k], f.probs[k], f.count[k] = boxes[k].ctypes.data, probs[k].ctypes.data, 20
+        f.json_path[0], f.json_path[1] = str(tmp_path / "g.json").encode(), str(tmp_path / "s.json").encode()
+        f.conf, f.rle_pool, f.rle_offsets = conf.ctypes.data, pool.ctypes.data, off.ctypes.data
+        assert lib.premvos_write_frame_files_host(C.byref(f)) == 0, lib.premvos_last_error()
+        with np.errstate(all="ignore"):
+            g = results_json(boxes[0:1], probs[0:1], np.array([20]), scale, (h, w))[0]
+            s = results_json(boxes[1:2], probs[1:2], np.array([20]), scale, (h, w))[0]
+        assert (tmp_path / "g.json").read_text() == json.dumps(g), rep
+        assert (tmp_path / "s.json").read_text() == json.dumps(s), rep
