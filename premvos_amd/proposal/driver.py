@@ -151,15 +151,19 @@ def _cv_resize_f32(img: np.ndarray, dst_w: int, dst_h: int) -> np.ndarray:
 
 
 def fill_full_mask(box, mask, shape) -> np.ndarray:
-    """eval.py:35-58."""
-    x0, y0 = list(map(int, box[:2] + 0.5))
-    x1, y1 = list(map(int, box[2:] - 0.5))
-    x1, y1 = max(x0, x1), max(y0, y1)
-    w, h = x1 + 1 - x0, y1 + 1 - y0
-    m = (_cv_resize_f32(np.ascontiguousarray(mask, np.float32), w, h) > 0.5).astype("uint8")
-    ret = np.zeros(shape, dtype="uint8")
-    ret[y0:y1 + 1, x0:x1 + 1] = m[:max(0, min(h, shape[0] - y0)), :max(0, min(w, shape[1] - x0))]
-    return ret
+    """The mask head's M x M probabilities of one detection pasted into a frame-sized uint8 mask (eval.py:35-58; MODE_MASK only).
+    Pixel columns [floor(x0 + 0.5), floor(x1 - 0.5)] (at least one) and the rows likewise receive the probabilities resized to
+    that extent (cv2.resize INTER_LINEAR on float32) and thresholded at 0.5; the part of the box that lies beyond the frame's
+    right / bottom edge is dropped."""
+    corner = np.asarray(box)                     # (the +- 0.5 in the box's own dtype, then int() = truncation, as eval.py:47-49)
+    first = np.trunc(corner[:2] + 0.5).astype(np.int64)
+    last = np.maximum(np.trunc(corner[2:] - 0.5).astype(np.int64), first)
+    (x_lo, y_lo), (cols, rows) = first, last - first + 1
+    pasted = _cv_resize_f32(np.ascontiguousarray(mask, np.float32), int(cols), int(rows)) > 0.5
+    frame = np.zeros(shape, dtype=np.uint8)
+    keep_r, keep_c = max(0, min(int(rows), shape[0] - int(y_lo))), max(0, min(int(cols), shape[1] - int(x_lo)))
+    frame[y_lo:y_lo + keep_r, x_lo:x_lo + keep_c] = pasted[:keep_r, :keep_c]
+    return frame
 
 
 def clip_boxes(boxes: np.ndarray, shape) -> np.ndarray:
