@@ -505,8 +505,8 @@ class DeviceGather:
     # ---- the merge rank's side ------------------------------------------------------------------------------------------
     def _take_host(self, writer) -> torch.Tensor:
         """A page-locked host buffer for one chunk's prefix (flow, detections, conf, run boundaries): from the pool the writer
-        threads return them to, or a new one while fewer than 2 x world + 2 exist (a round in flight + a round being written)."""
-        import time
+        threads return them to (filled at start-up on the merge rank), or a new one while fewer than 2 x world + 2 exist (a round
+        in flight + a round being written)."""
         while True:
             try:
                 return self._free.get_nowait()
@@ -524,7 +524,6 @@ class DeviceGather:
             except queue.Empty:                       # (only the writer threads return buffers: do not outwait their failure)
                 if getattr(writer, "_err", None) is not None:
                     raise RuntimeError("the file writer failed while chunks were waiting for host buffers") from writer._err
-            time.sleep(0)
 
     def decode_round(self, k: int, bufs, out: str, writer) -> int:
         """Merge rank: every rank's buffer of round ``k`` -> files.  Returns the number of files submitted.

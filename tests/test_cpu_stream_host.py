@@ -259,3 +259,28 @@ def test_writer_threads_run_every_call_count_their_time_and_report_the_first_err
     with pytest.raises(ValueError):
         bad.close()
     assert iop.writer_threads() == 1 and 1 <= iop.writer_threads(merge_rank=True) <= 4
+
+
+def test_merge_rank_does_not_outwait_a_failed_writer(tmp_path, monkeypatch):
+    """The host buffers of the merge rank come back from the writer threads.  When a writer call fails (disk full), the calls behind
+    it are skipped and their buffers never return: the exchange thread must see that and raise, not wait for a buffer for ever."""
+    twins, torch = _np_twins()
+    from premvos_amd import io_pipeline as iop
+    from PIL import Image
+    d = tmp_path / "JPEGImages" / "clip"
+    d.mkdir(parents=True)
+    for t in range(2):
+        Image.fromarray(np.zeros((8, 10, 3), np.uint8)).save(d / f"{t:05d}.png")
+    dg = stream.DeviceGather(type("P", (), {"batch": 2})(), [str(d) + "/"], [[(0, 0, 2)]], 0, 1, "cpu", **twins)
+    monkeypatch.setattr(dg, "_finish_frame_py", lambda *a, **k: (_ for _ in ()).throw(OSError("No space left on device")))
+    monkeypatch.setenv("PREMVOS_HOST_FILES", "py")
+    r = dg.staging()
+    buf = dg.x.gathered_slot(dg.x.exchange_async(r))
+    wr = iop.Writer(threads=1)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="file writer failed"):
+        for _ in range(12):                                    # 4 buffers exist at world 1; none comes back after the failure
+            dg.decode_round(0, buf, str(tmp_path / "out"), wr)
+    assert time.time() - t0 < 10
+    with pytest.raises(OSError):
+        wr.close()
