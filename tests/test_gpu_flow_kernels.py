@@ -132,6 +132,44 @@ def test_corr_tiled_multi_tile_shapes(c, h, w):
     assert torch.all(out.buf[..., 81:] == 7.0)          # nothing written beyond the 81 channels
 
 
+def test_corr_instantiations_write_the_same_bits():
+    """Round 6: the cost volume is a template over (tile, channels per LDS chunk, waves per SIMD, prefetch, pixels per thread) and the
+    launcher picks an instantiation by shape (variant 5 for C <= 32 or small maps, 11 = two pixels per thread for large 64-channel
+    maps, 0 = the round-2 form elsewhere).  PREMVOS_CORR_VARIANT forces one (read once per process: one subprocess each).  On ragged
+    shapes -- partial tiles right and below, a partial last chunk, a destination window that is not 16-byte aligned, the copy of f1
+    -- every instantiation must write the bits of the round-2 form (same products, same order), and those match the oracle."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from premvos_amd import ops
+for c, h, w, off in ((32, 37, 70, 4), (64, 21, 45, 0), (20, 9, 33, 3), (96, 17, 40, 8)):
+    g = torch.Generator().manual_seed(c + h)
+    f1 = torch.randn((3, h, w, c + (-c) %% 4), generator=g).cuda()
+    f2 = torch.randn((3, h, w, c + (-c) %% 4), generator=g).cuda()
+    out = ops.NHWC.alloc(3, h, w, off + 81 + c + 5)
+    out.buf.fill_(3.0)
+    ops.corr(ops.NHWC(f1, c=c), ops.NHWC(f2, c=c), out.slice(off, 81 + c), 4, 0.1, True)
+    torch.cuda.synchronize()
+    print(int(out.buf.view(torch.int32).to(torch.int64).sum().item()), float(out.buf[..., off:off + 81].abs().max().item()))
+""" % repo
+    outs = {}
+    for v in ("0", "2", "5", "9", "11", "13", ""):
+        env = dict(os.environ, PYTHONPATH=repo)
+        env.pop("PREMVOS_CORR_VARIANT", None)
+        if v:
+            env["PREMVOS_CORR_VARIANT"] = v
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[v] = [ln for ln in r.stdout.splitlines() if ln and ln[0] in "-0123456789"]
+        assert len(outs[v]) == 4
+    for v, lines in outs.items():
+        assert lines == outs["0"], (v, lines, outs["0"])
+
+
 def test_corr_unaligned_destination_window():
     """A channel window that does not start on a 16-byte boundary takes the 4-byte store path."""
     ops = _ops()
